@@ -1,0 +1,69 @@
+"""The search oracle (oracle/wp_mcts.py) against golden vectors recorded from the imported reference WP_MCTS
+(tests/golden/gen_search.py): inherited visits, raw child visit counts, chosen action, pi and MT19937 stream position
+must all be bit-identical, move by move."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import evaluators
+from oracle.go_oracle import OracleGoEnv
+from oracle.wp_mcts import OracleSearch
+
+
+def _load(golden_dir, name):
+    with np.load(os.path.join(golden_dir, name)) as z:
+        return {k: z[k] for k in z.files}
+
+
+def replay_case(blob, tag, fn, max_moves=None):
+    name, seed, sims = tag.split("_")
+    seed, sims = int(seed[1:]), int(sims[1:])
+    env = OracleGoEnv()
+    rng = np.random.RandomState(seed)
+    s = OracleSearch(env, fn, rng, num_simulation=sims)
+    n_moves = len(blob[f"{tag}/action"])
+    if max_moves:
+        n_moves = min(n_moves, max_moves)
+    for m in range(n_moves):
+        n0 = s.root.n
+        a, pi, obs, info = s.search_move()
+        raw = np.array([s.root.kids[i].n if i in s.root.kids else 0 for i in range(82)])
+        assert n0 == blob[f"{tag}/n0"][m], (tag, m)
+        assert (raw == blob[f"{tag}/counts"][m]).all(), (tag, m)
+        assert a == blob[f"{tag}/action"][m], (tag, m)
+        assert (pi == blob[f"{tag}/pi"][m]).all(), (tag, m)
+        assert s.root.n == blob[f"{tag}/root_n"][m]
+        done = s.advance(a)
+        assert rng.get_state()[2] == blob[f"{tag}/pos"][m], (tag, m)
+        assert int(done) == blob[f"{tag}/done"][m]
+    return s, rng
+
+
+@pytest.mark.parametrize("tag", ["flat_s0_n64", "sharp_s1_n64", "flat_s5_n16", "sharp_s6_n8"])
+def test_full_games(golden_dir, tag):
+    blob = _load(golden_dir, "search_analytic.npz")
+    s, rng = replay_case(blob, tag, evaluators.BY_NAME[tag.split("_")[0]])
+    assert (rng.get_state()[1] == blob[f"{tag}/final_key"]).all()
+    env = s.env
+    score, terr = env.getScoreAndTerritory(s.root.state)
+    assert score == blob[f"{tag}/final_score"] and (terr.astype(np.int8) == blob[f"{tag}/final_terr"]).all()
+    assert env.getWinner(s.root.state) == blob[f"{tag}/winner"]
+
+
+@pytest.mark.parametrize("tag,moves", [("sharp_s2_n210", 12), ("flat_s3_n400", 4), ("sharp_s4_n400", 4)])
+def test_deep_search(golden_dir, tag, moves):
+    blob = _load(golden_dir, "search_analytic.npz")
+    replay_case(blob, tag, evaluators.BY_NAME[tag.split("_")[0]], max_moves=moves)
+
+
+def test_replayed_network(golden_dir):
+    """Real TransGoNetwork outputs, recorded per evaluated leaf; replayed through a lookup keyed by the bit-packed
+    observation, so the oracle must also reproduce every leaf observation exactly."""
+    blob = _load(golden_dir, "search_replay.npz")
+    table = {o.tobytes(): (p, v) for o, p, v in zip(blob["log_obs"], blob["log_policy"], blob["log_value"])}
+
+    def lookup(obs):
+        ps, vs = zip(*[table[np.packbits(o.astype(np.uint8).reshape(-1)).tobytes()] for o in obs])
+        return np.stack(ps), np.stack(vs)
+    replay_case(blob, "real_s11_n64", lookup)

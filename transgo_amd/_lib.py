@@ -1,0 +1,98 @@
+"""ctypes loader for libtransgo_hip.so (the C ABI declared in include/transgo_hip.h).
+
+There is no CPU fallback anywhere in this package: if the shared library is missing, or no GPU is visible when a
+context is created, the caller gets an exception."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtransgo_hip.so")
+
+
+class TgConfig(ctypes.Structure):
+    _fields_ = [("board_size", ctypes.c_int32), ("encode_dim", ctypes.c_int32), ("max_step", ctypes.c_int32),
+                ("komi", ctypes.c_float), ("n_games", ctypes.c_int32), ("num_simulation", ctypes.c_int32),
+                ("parallel_readouts", ctypes.c_int32), ("wu_loss", ctypes.c_int32), ("c_puct1", ctypes.c_double),
+                ("c_puct2", ctypes.c_double), ("arena_slots", ctypes.c_int32), ("net_blocks", ctypes.c_int32),
+                ("net_filters", ctypes.c_int32), ("device", ctypes.c_int32), ("reserved", ctypes.c_int32 * 8)]
+
+
+class TransgoError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/transgo_hip.h declares
+_vp, _i32p, _u8p, _f32p = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p
+SIGNATURES = {
+    "tg_version": (ctypes.c_int, []),
+    "tg_config_default": (None, [ctypes.POINTER(TgConfig)]),
+    "tg_create": (ctypes.c_int, [ctypes.POINTER(TgConfig), ctypes.POINTER(ctypes.c_void_p)]),
+    "tg_destroy": (None, [_vp]),
+    "tg_last_error": (ctypes.c_char_p, [_vp]),
+    "tg_sync": (ctypes.c_int, [_vp]),
+    "tg_state_size": (ctypes.c_int, [_vp]),
+    "tg_env_reset": (ctypes.c_int, [_vp, _vp, ctypes.c_int]),
+    "tg_env_step": (ctypes.c_int, [_vp, _vp, _vp, _i32p, ctypes.c_int, _u8p, _u8p]),
+    "tg_env_query": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _u8p, _u8p, _f32p, _f32p, _f32p, _i32p, _i32p, _u8p]),
+    "tg_env_show": (ctypes.c_int, [_vp, _vp]),
+}
+
+
+def load():
+    """Load the library (once).  Raises TransgoError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TransgoError(f"{LIB_PATH} not found: build it with `make -C transgo_amd/csrc` "
+                           "(or python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(lib, ctx, rc):
+    if rc != 0:
+        msg = lib.tg_last_error(ctx)
+        raise TransgoError(f"libtransgo_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def default_config():
+    cfg = TgConfig()
+    load().tg_config_default(ctypes.byref(cfg))
+    return cfg
+
+
+class Context:
+    """Owns one tg_ctx."""
+
+    def __init__(self, cfg):
+        self.lib = load()
+        self.cfg = cfg
+        h = ctypes.c_void_p()
+        rc = self.lib.tg_create(ctypes.byref(cfg), ctypes.byref(h))
+        if rc != 0:
+            msg = self.lib.tg_last_error(None)
+            raise TransgoError(f"tg_create failed ({rc}): {msg.decode() if msg else '?'}")
+        self.h = h
+        self.state_size = self.lib.tg_state_size(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def call(self, name, *args):
+        check(self.lib, self.h, getattr(self.lib, name)(self.h, *args))

@@ -1,0 +1,474 @@
+// board_dev.h -- wave-cooperative Go board engine for gfx950 (one 64-lane wavefront = one board).
+//
+// Replaces, behaviour-for-behaviour, the reference rules engine /root/reference/GoEnv/cpp_src (board.cc, board_feature.cc,
+// go_env.cc; cited per function).  The mechanism is different by design: the reference keeps incremental liberty
+// counts on linked lists of stones (board.cc:217-428, AoS, 1188 B per state); here a state is two bitboards plus 16 B
+// of scalars (48 B at 9x9, 112 B at 19x19), lanes own points (point p = slot*64 + lane), groups are found by min-label
+// propagation with pointer jumping through LDS, and liberties are counted with LDS atomics, so every per-point answer
+// (legal, suicide, liberty class, eye, alive) is a lane-local read of LDS tables.  New bitboards come straight out of
+// 64-bit ballots.
+//
+// A workgroup is exactly one wavefront (64 threads): __syncthreads() is then a single-wave s_barrier that orders the
+// LDS traffic between lanes at negligible cost, and games never wait for each other's flood-fill trip counts.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tg {
+
+constexpr int kEmpty = 0, kBlack = 1, kWhite = 2, kWall = 3;
+constexpr int kPass = -1, kResign = -2, kInvalid = -3;     // go_comm.h:24-26
+constexpr uint32_t kNone = 0xFFFFu;
+
+struct RulesCfg {
+    int max_step;     // go_env.cc:11
+    float komi;       // go_env.cc:12
+    int encode_dim;   // 9 / 10 / 13 (go_env.cc:96-115)
+};
+
+template <int S> struct Geo {
+    static constexpr int P = S * S;
+    static constexpr int A = P + 1;
+    static constexpr int NW = (P + 63) / 64;     // bitboard words == points per lane
+    static constexpr int PPAD = NW * 64;
+};
+
+// Game state: value type, caller-visible as an opaque blob through the C ABI (replaces GoState, go_env.h:15-18).
+template <int S> struct alignas(16) BoardState {
+    uint64_t bb[2][Geo<S>::NW];   // [0] black, [1] white; bit p of the row-major point index
+    int16_t last_move1;           // board.h:47
+    int16_t last_move2;           // board.h:48
+    int16_t ko_location;          // board.h:51
+    int16_t ko_age;               // board.h:53
+    uint16_t step_count;          // board.h:46
+    uint8_t ko_color;             // board.h:52
+    uint8_t next_player;          // board.h:45
+    uint8_t terminated;           // go_env.h:17
+    uint8_t pad[3];
+};
+static_assert(sizeof(BoardState<9>) == 48, "9x9 state is 48 B");
+static_assert(sizeof(BoardState<19>) == 112, "19x19 state is 112 B");
+
+// LDS scratch of one wave.
+template <int S> struct WaveLds {
+    uint16_t col[Geo<S>::PPAD + 64];   // colour per point
+    uint16_t lab[Geo<S>::PPAD + 64];   // group label per point (kNone for unlabelled)
+    uint32_t cnt[Geo<S>::PPAD + 64];   // per label: liberties (or touch mask when scoring)
+    uint32_t aux[Geo<S>::PPAD + 64];   // per label: good-eye count; per point: eye flag in bit 16
+};
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
+
+// Everything a lane knows about its NW points.
+template <int S> struct BoardWave {
+    using G = Geo<S>;
+    static constexpr int NW = G::NW;
+    WaveLds<S>* L;
+    int lane;
+    int pt[NW];         // point index (may be >= P: invalid)
+    uint8_t nbv[NW];    // bit d set: neighbour d on board (d: 0 L, 1 U, 2 R, 3 D = go_comm.h:44-45); bits 4-7: diagonals
+    uint8_t col[NW];    // colour of own point (kWall if invalid)
+
+    __device__ __forceinline__ void init(WaveLds<S>* lds) {
+        L = lds;
+        lane = lane_id();
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            int p = k * 64 + lane;
+            pt[k] = p;
+            int x = p % S, y = p / S;
+            uint8_t v = 0;
+            if (p < G::P) {
+                if (x > 0) v |= 1;
+                if (y > 0) v |= 2;
+                if (x < S - 1) v |= 4;
+                if (y < S - 1) v |= 8;
+                // diagonals in the order of go_comm.h:49-50: (-1,-1) (-1,+1) (+1,+1) (+1,-1)
+                if (x > 0 && y > 0) v |= 16;
+                if (x > 0 && y < S - 1) v |= 32;
+                if (x < S - 1 && y < S - 1) v |= 64;
+                if (x < S - 1 && y > 0) v |= 128;
+            }
+            nbv[k] = v;
+        }
+    }
+    __device__ __forceinline__ static int nb_off(int d) { return d == 0 ? -1 : d == 1 ? -S : d == 2 ? 1 : S; }
+    __device__ __forceinline__ static int dg_off(int d) { return d == 0 ? -S - 1 : d == 1 ? S - 1 : d == 2 ? S + 1 : -S + 1; }
+
+    // colours from bitboards -> registers + LDS
+    __device__ __forceinline__ void load_colors(const uint64_t* bbB, const uint64_t* bbW) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            int c = kWall;
+            if (pt[k] < G::P) c = ((bbB[k] >> lane) & 1) ? kBlack : ((bbW[k] >> lane) & 1) ? kWhite : kEmpty;
+            col[k] = (uint8_t)c;
+            L->col[pt[k]] = (uint16_t)c;
+        }
+        __syncthreads();
+    }
+    // after editing col[] in registers
+    __device__ __forceinline__ void publish_colors() {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NW; ++k) L->col[pt[k]] = col[k];
+        __syncthreads();
+    }
+    __device__ __forceinline__ void to_bitboards(uint64_t* bbB, uint64_t* bbW) const {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            bbB[k] = ballot64(col[k] == kBlack);
+            bbW[k] = ballot64(col[k] == kWhite);
+        }
+    }
+
+    // Connected components by min-label propagation + pointer jumping.  with_empty: empty regions are labelled too
+    // (needed for Tromp-Taylor scoring only).  Result in L->lab.
+    __device__ void label_groups(bool with_empty) {
+        uint32_t lab[NW];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            bool on = (col[k] == kBlack || col[k] == kWhite || (with_empty && col[k] == kEmpty));
+            lab[k] = on ? (uint32_t)pt[k] : kNone;
+            L->lab[pt[k]] = (uint16_t)lab[k];
+        }
+        __syncthreads();
+        for (int it = 0; it < G::P + 2; ++it) {       // bounded: converges in far fewer rounds
+            bool ch = false;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                if (lab[k] == kNone) continue;
+                uint32_t m = lab[k];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    if (!(nbv[k] >> d & 1)) continue;
+                    int q = pt[k] + nb_off(d);
+                    if (L->col[q] == col[k]) { uint32_t t = L->lab[q]; m = t < m ? t : m; }
+                }
+                ch |= (m != lab[k]);
+                lab[k] = m;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NW; ++k) L->lab[pt[k]] = (uint16_t)lab[k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NW; ++k)
+                if (lab[k] != kNone) { uint32_t t = L->lab[lab[k]]; lab[k] = t < lab[k] ? t : lab[k]; }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NW; ++k) L->lab[pt[k]] = (uint16_t)lab[k];
+            __syncthreads();
+            if (!__any(ch)) break;
+        }
+    }
+
+    // Liberties per group label into L->cnt (equivalent observable of Block::liberties, board.h:23).
+    __device__ void count_liberties() {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) { L->cnt[pt[k]] = 0; L->aux[pt[k]] = 0; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            if (col[k] != kEmpty) continue;
+            uint32_t seen[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                seen[d] = kNone;
+                if (!(nbv[k] >> d & 1)) continue;
+                int q = pt[k] + nb_off(d);
+                uint32_t l = L->lab[q];
+                if (L->col[q] == kEmpty) l = kNone;
+                bool dup = false;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (e < d && seen[e] == l) dup = true;
+                seen[d] = l;
+                if (l != kNone && !dup) atomicAdd(&L->cnt[l], 1u);
+            }
+        }
+        __syncthreads();
+    }
+    __device__ __forceinline__ void analyze() { label_groups(false); count_liberties(); }
+
+    __device__ __forceinline__ int lib_at(int q) const { return (int)L->cnt[L->lab[q]]; }
+
+    // board.cc:130-158 isSuicideMove for `player` at own slot k (point must be empty).
+    __device__ __forceinline__ bool suicide(int k, int player) const {
+        bool s = true;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            if (!(nbv[k] >> d & 1)) continue;
+            int q = pt[k] + nb_off(d);
+            int c = L->col[q];
+            if (c == kEmpty) { s = false; continue; }
+            int l = lib_at(q);
+            if (c == player) { if (l > 1) s = false; }
+            else if (l == 1) s = false;
+        }
+        return s;
+    }
+    // board.cc:432-464 TryPlay for board points, on an analysed position.
+    template <class St> __device__ __forceinline__ bool legal(int k, const St& st, int player) const {
+        if (col[k] != kEmpty) return false;
+        if (st.ko_location == pt[k] && st.ko_age == 0 && st.ko_color == player) return false;   // board.cc:198-200
+        return !suicide(k, player);
+    }
+    // board.cc:665-714 isTrueEye
+    __device__ __forceinline__ bool true_eye(int k, int player) const {
+        if (col[k] != kEmpty) return false;
+        bool eye = true;
+        int nwall = 0, nopp = 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            if (nbv[k] >> d & 1) { if (L->col[pt[k] + nb_off(d)] != player) eye = false; }
+            if (nbv[k] >> (4 + d) & 1) { if (L->col[pt[k] + dg_off(d)] == (3 - player)) ++nopp; }
+            else ++nwall;
+        }
+        bool fake = (nwall > 0 && nopp >= 1) || (nwall == 0 && nopp >= 2);
+        return eye && !fake;
+    }
+
+    // board.cc:731-817 GivenBlockLives for every group of colour `c` at once.  Afterwards bit 0 of aux[label] >> 17
+    // ... see alive_at().  Requires analyze().  Uses aux: per point bit 16 = true eye of colour c; low 16 bits per
+    // label = number of qualifying eyes.
+    __device__ void mark_alive(int c) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) L->aux[pt[k]] = 0;
+        __syncthreads();
+        bool eye[NW];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            eye[k] = (pt[k] < G::P) && true_eye(k, c);
+            if (eye[k]) atomicOr(&L->aux[pt[k]], 1u << 16);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            if (!eye[k]) continue;
+            uint32_t gl[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                gl[d] = kNone;
+                if (!(nbv[k] >> d & 1)) continue;
+                uint32_t g = L->lab[pt[k] + nb_off(d)];
+                bool dup = false;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (e < d && gl[e] == g) dup = true;
+                gl[d] = g;
+                if (dup) continue;
+                // candidate eye `pt[k]` judged for group g (board.cc:775-811)
+                int nb = 0, nt = 0;
+#pragma unroll
+                for (int dd = 0; dd < 4; ++dd) {
+                    if (!(nbv[k] >> (4 + dd) & 1)) { ++nb; continue; }
+                    int q = pt[k] + dg_off(dd);
+                    int cq = L->col[q];
+                    if (cq == c) { ++nt; continue; }
+                    if (cq != kEmpty || !(L->aux[q] >> 16 & 1)) continue;
+                    // q is a true eye of colour c: is it a candidate of group g (adjacent to g)?
+                    int qx = q % S, qy = q / S;
+                    bool adj = false;
+                    if (qx > 0 && L->lab[q - 1] == g) adj = true;
+                    if (qy > 0 && L->lab[q - S] == g) adj = true;
+                    if (qx < S - 1 && L->lab[q + 1] == g) adj = true;
+                    if (qy < S - 1 && L->lab[q + S] == g) adj = true;
+                    if (adj) ++nt;
+                }
+                if ((nb >= 1 && nb + nt == 4) || (nb == 0 && nt >= 3)) atomicAdd(&L->aux[g], 1u);
+            }
+        }
+        __syncthreads();
+    }
+    __device__ __forceinline__ bool alive_at(int k) const {
+        uint32_t g = L->lab[pt[k]];
+        return (int)L->cnt[g] >= 2 && (L->aux[g] & 0xFFFFu) >= 2;
+    }
+};
+
+// ---- state-level operations (all lanes of the wave call these together; scalars are wave-uniform) ----------------------
+
+template <int S> __device__ __forceinline__ void state_reset(BoardState<S>& st) {     // board.cc:13-26
+#pragma unroll
+    for (int k = 0; k < Geo<S>::NW; ++k) { st.bb[0][k] = 0; st.bb[1][k] = 0; }
+    st.last_move1 = kInvalid; st.last_move2 = kInvalid; st.ko_location = kInvalid; st.ko_age = 0;
+    st.step_count = 1; st.ko_color = 0; st.next_player = kBlack; st.terminated = 0;
+    st.pad[0] = st.pad[1] = st.pad[2] = 0;
+}
+
+template <int S> __device__ __forceinline__ bool point_in(const uint64_t* bb, int p) { return (bb[p >> 6] >> (p & 63)) & 1; }
+
+// go_env.cc:44-80 Step_ + board.cc:546-653 Play.  `st` is updated in place (wave-uniform copy held by every lane).
+// action: [0,P) point, P or -1 pass, -2 resign.  Returns done; *ok = move accepted.  If `check` is false the caller
+// guarantees legality (tree search only ever plays moves from a legal list) and the test is skipped.
+template <int S>
+__device__ bool state_step(BoardWave<S>& bw, BoardState<S>& st, int action, const RulesCfg& cfg, bool check, bool* ok) {
+    using G = Geo<S>;
+    *ok = true;
+    if (st.terminated) return true;                                   // go_env.cc:52-55
+    if (action == G::P) action = kPass;                               // go_env.cc:56-57
+    const int player = st.next_player, other = 3 - player;
+    if (action == kPass || action == kResign) {                       // board.cc:554-558 (ko untouched)
+        st.next_player = (uint8_t)other;
+        st.last_move2 = st.last_move1; st.last_move1 = (int16_t)action; st.step_count++;
+        bool done = st.step_count > 1 && ((st.last_move1 == kPass && st.last_move2 == kPass) || st.last_move1 == kResign);
+        if (done || st.step_count > cfg.max_step) { st.terminated = 1; return true; }
+        return false;
+    }
+    if (action < 0 || action > G::P) { *ok = false; return false; }
+    bw.load_colors(st.bb[0], st.bb[1]);
+    bw.analyze();
+    const int ak = action >> 6, al = action & 63;
+    if (check) {
+        bool mine = false;
+#pragma unroll
+        for (int k = 0; k < G::NW; ++k) if (k == ak && bw.lane == al) mine = bw.legal(k, st, player);
+        uint64_t b = ballot64(mine);
+        if (b == 0) { *ok = false; return false; }                    // go_env.cc:75-79: state unchanged
+    }
+    // pre-move neighbourhood of the played point (board.cc:90-127), evaluated by every lane redundantly (uniform)
+    const int ax = action % S, ay = action / S;
+    int self_lib = 0, n11 = 0, ko_at = kInvalid;
+    bool own_nb = false;
+    uint32_t cap[4] = {kNone, kNone, kNone, kNone};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        bool v = d == 0 ? ax > 0 : d == 1 ? ay > 0 : d == 2 ? ax < S - 1 : ay < S - 1;
+        if (!v) continue;
+        int q = action + BoardWave<S>::nb_off(d);
+        int c = bw.L->col[q];
+        if (c == kEmpty) { ++self_lib; continue; }
+        if (c == player) { own_nb = true; continue; }
+        uint32_t g = bw.L->lab[q];
+        if (bw.L->cnt[g] == 1) {
+            cap[d] = g;                                               // captured: its only liberty is `action`
+            // single-stone group <=> no same-colour neighbour (board.cc:181-187)
+            int qx = q % S, qy = q / S;
+            bool single = !((qx > 0 && bw.L->col[q - 1] == other) || (qy > 0 && bw.L->col[q - S] == other) ||
+                            (qx < S - 1 && bw.L->col[q + 1] == other) || (qy < S - 1 && bw.L->col[q + S] == other));
+            if (single) { ++n11; ko_at = q; }
+        }
+    }
+    if (self_lib == 0 && !own_nb && n11 == 1) {                       // board.cc:561-570
+        st.ko_location = (int16_t)ko_at; st.ko_color = (uint8_t)other; st.ko_age = 0;
+    } else {
+        st.ko_age++;
+    }
+#pragma unroll
+    for (int k = 0; k < G::NW; ++k) {
+        if (bw.col[k] == other) {
+            uint32_t g = bw.L->lab[bw.pt[k]];
+            if (g == cap[0] || g == cap[1] || g == cap[2] || g == cap[3]) bw.col[k] = kEmpty;   // board.cc:606-630
+        }
+        if (k == ak && bw.lane == al) bw.col[k] = (uint8_t)player;
+    }
+    bw.to_bitboards(st.bb[0], st.bb[1]);
+    st.next_player = (uint8_t)other;                                  // board.cc:536-542
+    st.last_move2 = st.last_move1; st.last_move1 = (int16_t)action; st.step_count++;
+    if (st.step_count > cfg.max_step) { st.terminated = 1; return true; }   // go_env.cc:67
+    return false;
+}
+
+// Legal points of the side to move as bitboard words (board.cc:467-489).  Position must be loaded + analysed.
+template <int S> __device__ __forceinline__ void legal_words(const BoardWave<S>& bw, const BoardState<S>& st, uint64_t* out) {
+#pragma unroll
+    for (int k = 0; k < Geo<S>::NW; ++k) out[k] = ballot64(bw.pt[k] < Geo<S>::P && bw.legal(k, st, st.next_player));
+}
+
+// board_feature.cc:213-253 encode9/10/13 -> f32 planes [C][P] at `out` (plane-major, like the reference).
+// Position must be loaded + analysed.  Clobbers L->aux.
+template <int S> __device__ void encode_planes(BoardWave<S>& bw, const BoardState<S>& st, const RulesCfg& cfg, float* out) {
+    using G = Geo<S>;
+    const int C = cfg.encode_dim, me = st.next_player, op = 3 - me;
+    int pl_h2 = -1, pl_ko = 7, pl_eye = 8, pl_oeye = -1, pl_live = (C == 9) ? -1 : 9, pl_olive = -1;
+    if (C == 13) { pl_h2 = 7; pl_ko = 8; pl_eye = 9; pl_oeye = 10; pl_live = 11; pl_olive = 12; }
+    // plane indices (runtime C): static arrays below are only ever indexed with compile-time constants
+    bool live_me[G::NW], live_op[G::NW];
+#pragma unroll
+    for (int k = 0; k < G::NW; ++k) { live_me[k] = false; live_op[k] = false; }
+    // liberty classes, ko/suicide and eyes first: mark_alive() clobbers nothing they need, but keep the order explicit
+    int cls[G::NW];          // 0/1/2 liberty class of a stone, -1 otherwise
+    bool kosu[G::NW], eye_me[G::NW], eye_op[G::NW];
+#pragma unroll
+    for (int k = 0; k < G::NW; ++k) {
+        cls[k] = -1; kosu[k] = false; eye_me[k] = false; eye_op[k] = false;
+        if (bw.pt[k] >= G::P) continue;
+        const int c = bw.col[k];
+        if (c == kBlack || c == kWhite) {                             // board_feature.cc:17-41
+            int l = bw.lib_at(bw.pt[k]);
+            cls[k] = l == 1 ? 0 : l == 2 ? 1 : l >= 3 ? 2 : -1;
+        } else {
+            bool ko = (st.ko_age == 0 && st.ko_location == bw.pt[k]);   // board.cc:205-213 (ko_color ignored)
+            kosu[k] = ko || bw.suicide(k, me);                          // board.cc:520-533, board_feature.cc:69-89
+            eye_me[k] = bw.true_eye(k, me);                             // board_feature.cc:142-161
+            if (pl_oeye >= 0) eye_op[k] = bw.true_eye(k, op);
+        }
+    }
+    if (pl_live >= 0) {                                                 // board_feature.cc:164-182
+        bw.mark_alive(me);
+#pragma unroll
+        for (int k = 0; k < G::NW; ++k) live_me[k] = (bw.col[k] == me) && bw.alive_at(k);
+    }
+    if (pl_olive >= 0) {
+        bw.mark_alive(op);
+#pragma unroll
+        for (int k = 0; k < G::NW; ++k) live_op[k] = (bw.col[k] == op) && bw.alive_at(k);
+    }
+#pragma unroll
+    for (int k = 0; k < G::NW; ++k) {
+        const int p = bw.pt[k];
+        if (p >= G::P) continue;
+        const bool mine = bw.col[k] == me, theirs = bw.col[k] == op;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            out[j * G::P + p] = (mine && cls[k] == j) ? 1.f : 0.f;
+            out[(3 + j) * G::P + p] = (theirs && cls[k] == j) ? 1.f : 0.f;
+        }
+        out[6 * G::P + p] = (st.last_move1 == p) ? 1.f : 0.f;          // board_feature.cc:92-100
+        if (pl_h2 >= 0) out[pl_h2 * G::P + p] = (st.last_move2 == p) ? 1.f : 0.f;
+        out[pl_ko * G::P + p] = kosu[k] ? 1.f : 0.f;
+        out[pl_eye * G::P + p] = eye_me[k] ? 1.f : 0.f;
+        if (pl_oeye >= 0) out[pl_oeye * G::P + p] = eye_op[k] ? 1.f : 0.f;
+        if (pl_live >= 0) out[pl_live * G::P + p] = live_me[k] ? 1.f : 0.f;
+        if (pl_olive >= 0) out[pl_olive * G::P + p] = live_op[k] ? 1.f : 0.f;
+    }
+}
+
+// board.cc:822-958 getTTScore.  Loads colours itself.  Returns raw Tromp-Taylor area difference (0 on an empty board,
+// board.cc:932-935); owner[k] (optional, per lane slot): 1 black, 2 white, 3 dame.
+template <int S> __device__ float tromp_taylor(BoardWave<S>& bw, const BoardState<S>& st, uint8_t* owner) {
+    using G = Geo<S>;
+    bw.load_colors(st.bb[0], st.bb[1]);
+    bw.label_groups(true);
+#pragma unroll
+    for (int k = 0; k < G::NW; ++k) bw.L->cnt[bw.pt[k]] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < G::NW; ++k) {
+        if (bw.col[k] != kEmpty) continue;
+        uint32_t touch = 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            if (!(bw.nbv[k] >> d & 1)) continue;
+            int c = bw.L->col[bw.pt[k] + BoardWave<S>::nb_off(d)];
+            if (c == kBlack || c == kWhite) touch |= (uint32_t)c;
+        }
+        if (touch) atomicOr(&bw.L->cnt[bw.L->lab[bw.pt[k]]], touch);
+    }
+    __syncthreads();
+    int nb = 0, nw = 0, ns = 0;
+#pragma unroll
+    for (int k = 0; k < G::NW; ++k) {
+        int o = 0;
+        if (bw.col[k] == kBlack || bw.col[k] == kWhite) o = bw.col[k];
+        else if (bw.col[k] == kEmpty) { uint32_t t = bw.L->cnt[bw.L->lab[bw.pt[k]]]; o = (t == 1) ? 1 : (t == 2) ? 2 : 3; }
+        if (owner) owner[k] = (uint8_t)o;
+        nb += __popcll(ballot64(o == 1 && bw.pt[k] < G::P));
+        nw += __popcll(ballot64(o == 2 && bw.pt[k] < G::P));
+        ns += __popcll(ballot64(bw.col[k] == kBlack || bw.col[k] == kWhite));
+    }
+    __syncthreads();
+    if (ns == 0) return 0.f;
+    return (float)(nb - nw);
+}
+
+}  // namespace tg

@@ -94,6 +94,69 @@ int tg_env_query(tg_ctx* ctx, const void* states, int n, uint8_t* legal, uint8_t
 /* Show (go_env.h:63): prints the board of one state to stdout. */
 int tg_env_show(tg_ctx* ctx, const void* state);
 
+
+/* NumPy legacy RandomState stream: key/pos are get_state()[1] / get_state()[2]. */
+typedef struct tg_mt19937 {
+    uint32_t key[624];
+    int32_t pos;
+} tg_mt19937;
+
+/* ---- 2. batched self-play engine (needs cfg.n_games > 0) -----------------------------------------------------------------
+ * G games advance in lock step.  One move of every game is:
+ *     tg_sp_begin_move -> { tg_sp_collect -> evaluate -> tg_sp_absorb } until no game is active
+ *                      -> tg_sp_root_info (visit counts) -> host picks moves -> tg_sp_play -> evaluate -> tg_sp_expand_roots
+ * "evaluate" is tg_sp_eval (network forward on the GPU) or, for parity tests with a stand-in evaluator,
+ * tg_sp_batch_obs + tg_sp_set_eval.  tg_sp_search runs the whole inner loop with the network.
+ * An evaluation batch is a compact array of rows; rows belong either to fresh roots or to the leaves of one wave. */
+
+/* WP_MCTS.reset_root (self_play.py:595-605) for every game (mask NULL) or the games with mask[g] != 0:
+ * empty board, np.random.seed(seeds[g]) for the game's stream.  Leaves a root batch pending. */
+int tg_sp_reset(tg_ctx* ctx, const uint32_t* seeds, const uint8_t* mask);
+
+int tg_sp_batch_rows(tg_ctx* ctx, int32_t* n_rows);                        /* rows of the pending batch */
+int tg_sp_batch_obs(tg_ctx* ctx, float* obs /*[n_rows][C][S][S]*/, int32_t n_rows);   /* env.encode of each row (self_play.py:798) */
+int tg_sp_set_eval(tg_ctx* ctx, const float* policy /*[n_rows][A]*/, const float* value /*[n_rows]*/, int32_t n_rows);
+int tg_sp_eval(tg_ctx* ctx);                                               /* model.main_prediction on the pending batch (self_play.py:777-786) */
+int tg_sp_expand_roots(tg_ctx* ctx);                                       /* root.expand with raw priors (self_play.py:603-605, :867-870) */
+
+/* get_action_probs prologue (self_play.py:659-663): Dirichlet(0.03) root noise when selfplay != 0, and the visit
+ * target N0 + num_simulation (<= 0: cfg.num_simulation). */
+int tg_sp_begin_move(tg_ctx* ctx, int selfplay, int num_simulation);
+
+/* Front half of WP_MCTS.run (self_play.py:616-646) for every active game.  n_active = games still below their
+ * target before this wave; n_rows = leaves awaiting evaluation. */
+int tg_sp_collect(tg_ctx* ctx, int32_t* n_active, int32_t* n_rows);
+/* Back half (self_play.py:651-654, :727-774). */
+int tg_sp_absorb(tg_ctx* ctx);
+/* while root.N < N0 + sims: run()  (self_play.py:662-664) with the network as evaluator. */
+int tg_sp_search(tg_ctx* ctx, int32_t* n_waves);
+
+/* visit counts per action (self_play.py:666-667), root visit total, side to move, ply counter, env.encode(root)
+ * (self_play.py:685).  Any pointer may be NULL. */
+int tg_sp_root_info(tg_ctx* ctx, int32_t* visits /*[G][A]*/, int32_t* root_n, int32_t* player, int32_t* step,
+                    float* obs /*[G][C][S][S]*/);
+/* One random_sample() from each game's stream: the draw inside np.random.choice(A, p=) (self_play.py:683). */
+int tg_sp_draw_uniform(tg_ctx* ctx, double* u /*[G]*/, const uint8_t* mask);
+int tg_sp_rng_state(tg_ctx* ctx, int game, tg_mt19937* out);
+/* update_with_action (self_play.py:857-872) for every unfinished game; done[g] = game over.  Leaves a root batch
+ * pending for the games whose new root was not yet expanded. */
+int tg_sp_play(tg_ctx* ctx, const int32_t* actions /*[G]*/, uint8_t* done /*[G]*/);
+/* getScoreAndTerritory / getWinner of the current root position (self_play.py:932-937). */
+int tg_sp_final(tg_ctx* ctx, float* score /*[G]*/, float* terr /*[G][S*S]*/, int32_t* winner /*[G]*/);
+/* Aggregate counters: completed simulations, evaluated leaves, summed selection depth, RNG words drawn by tie
+ * breaks, games in error, high-water mark of arena slots. */
+int tg_sp_stats(tg_ctx* ctx, uint64_t* sims, uint64_t* evals, uint64_t* depth_sum, uint64_t* tie_draws, int32_t* errors,
+                int32_t* max_slots);
+
+/* ---- 3. host-only NumPy-legacy MT19937 helpers ------------------------------------------------------------------------
+ * Same stream as np.random.RandomState: key/pos are get_state()[1] / get_state()[2].  No GPU needed. */
+
+void tg_host_mt_seed(tg_mt19937* s, uint32_t seed);                 /* np.random.seed(seed) */
+uint32_t tg_host_mt_next32(tg_mt19937* s);
+double tg_host_mt_random_sample(tg_mt19937* s);                     /* random_sample(): the draw inside choice(A, p=) (self_play.py:683) */
+int32_t tg_host_mt_choice_index(tg_mt19937* s, int32_t k);          /* index drawn by choice(list of k) (self_play.py:709) */
+int tg_host_mt_dirichlet(tg_mt19937* s, double alpha, int32_t n, double* out);   /* dirichlet([alpha]*n) (self_play.py:93) */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,104 @@
+"""HIP tree engine against (a) golden vectors recorded from the imported reference WP_MCTS and (b) the CPU oracle on
+many concurrent games: inherited root visits, raw visit counts, chosen action, pi and the MT19937 stream position
+must be bit-identical move by move.  The evaluator is a stand-in computed on the host from the observations the GPU
+produced (oracle/evaluators.py) or the recorded network outputs, so the network's own rounding is out of the picture."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import evaluators
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(golden_dir, name):
+    with np.load(os.path.join(golden_dir, name)) as z:
+        return {k: z[k] for k in z.files}
+
+
+def _engine(fn, G, sims, **kw):
+    from transgo_amd.engine import SelfPlayEngine
+    return SelfPlayEngine(G, num_simulation=sims, evaluator=fn, **kw)
+
+
+def _replay_fixture(blob, tag, fn, max_moves=None):
+    seed, sims = int(tag.split("_")[1][1:]), int(tag.split("_")[2][1:])
+    eng = _engine(fn, 1, sims)
+    eng.reset([seed])
+    n_moves = len(blob[f"{tag}/action"])
+    if max_moves:
+        n_moves = min(n_moves, max_moves)
+    for m in range(n_moves):
+        _, rn0, _, _, _ = eng.root_info(obs=False)
+        assert rn0[0] == blob[f"{tag}/n0"][m], (tag, m, "n0")
+        eng.search()
+        vis, rn, pl, st, ob = eng.root_info()
+        assert (vis[0] == blob[f"{tag}/counts"][m]).all(), (tag, m, "counts", vis[0], blob[f"{tag}/counts"][m])
+        assert rn[0] == blob[f"{tag}/root_n"][m] and pl[0] == blob[f"{tag}/player"][m] and st[0] == blob[f"{tag}/step"][m]
+        acts, pis = eng.choose_moves(vis, st)
+        assert acts[0] == blob[f"{tag}/action"][m], (tag, m, "action")
+        assert (pis[0] == blob[f"{tag}/pi"][m]).all(), (tag, m, "pi")
+        done = eng.play(acts)
+        assert eng.rng_state(0)[1] == blob[f"{tag}/pos"][m], (tag, m, "rng pos")
+        assert int(done[0]) == blob[f"{tag}/done"][m]
+    return eng
+
+
+@pytest.mark.parametrize("tag", ["flat_s0_n64", "sharp_s1_n64", "flat_s5_n16", "sharp_s6_n8"])
+def test_reference_full_games(golden_dir, tag):
+    blob = _load(golden_dir, "search_analytic.npz")
+    eng = _replay_fixture(blob, tag, evaluators.BY_NAME[tag.split("_")[0]])
+    key, _ = eng.rng_state(0)
+    assert (key == blob[f"{tag}/final_key"]).all()
+    score, terr, win = eng.final()
+    assert score[0] == blob[f"{tag}/final_score"] and (terr[0].astype(np.int8) == blob[f"{tag}/final_terr"]).all()
+    assert win[0] == blob[f"{tag}/winner"]
+    assert eng.stats()["errors"] == 0
+
+
+@pytest.mark.parametrize("tag", ["sharp_s2_n210", "flat_s3_n400", "sharp_s4_n400"])
+def test_reference_deep_search(golden_dir, tag):
+    blob = _load(golden_dir, "search_analytic.npz")
+    eng = _replay_fixture(blob, tag, evaluators.BY_NAME[tag.split("_")[0]])
+    assert eng.stats()["errors"] == 0
+
+
+def test_reference_replayed_network(golden_dir):
+    blob = _load(golden_dir, "search_replay.npz")
+    table = {o.tobytes(): (p, v) for o, p, v in zip(blob["log_obs"], blob["log_policy"], blob["log_value"])}
+
+    def lookup(obs):
+        ps, vs = zip(*[table[np.packbits(o.astype(np.uint8).reshape(-1)).tobytes()] for o in obs])
+        return np.stack(ps), np.stack(vs)
+    _replay_fixture(blob, "real_s11_n64", lookup)
+
+
+def test_many_games_vs_oracle():
+    """32 concurrent games with different seeds against 32 sequential oracle runs."""
+    from oracle.go_oracle import OracleGoEnv
+    from oracle.wp_mcts import OracleSearch
+    G, sims, moves = 32, 48, 24
+    fn = evaluators.sharp
+    seeds = np.arange(100, 100 + G)
+    eng = _engine(fn, G, sims)
+    eng.reset(seeds)
+    orcs = []
+    for s in seeds:
+        rng = np.random.RandomState(int(s))
+        orcs.append((OracleSearch(OracleGoEnv(), fn, rng, num_simulation=sims), rng))
+    for m in range(moves):
+        eng.search()
+        vis, rn, pl, st, ob = eng.root_info()
+        acts, pis = eng.choose_moves(vis, st)
+        for g, (o, rng) in enumerate(orcs):
+            a, pi, obs, info = o.search_move()
+            raw = np.array([o.root.kids[i].n if i in o.root.kids else 0 for i in range(82)])
+            assert (vis[g] == raw).all(), (g, m)
+            assert a == acts[g] and (pi == pis[g]).all() and (obs == ob[g]).all(), (g, m)
+            o.advance(a)
+        eng.play(acts)
+        for g, (o, rng) in enumerate(orcs):
+            assert eng.rng_state(g)[1] == rng.get_state()[2], (g, m)
+    st = eng.stats()
+    assert st["errors"] == 0 and st["sims"] > 0

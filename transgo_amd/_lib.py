@@ -17,6 +17,10 @@ class TgConfig(ctypes.Structure):
                 ("net_filters", ctypes.c_int32), ("device", ctypes.c_int32), ("reserved", ctypes.c_int32 * 8)]
 
 
+class TgMt19937(ctypes.Structure):
+    _fields_ = [("key", ctypes.c_uint32 * 624), ("pos", ctypes.c_int32)]
+
+
 class TransgoError(RuntimeError):
     pass
 
@@ -37,6 +41,27 @@ SIGNATURES = {
     "tg_env_step": (ctypes.c_int, [_vp, _vp, _vp, _i32p, ctypes.c_int, _u8p, _u8p]),
     "tg_env_query": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _u8p, _u8p, _f32p, _f32p, _f32p, _i32p, _i32p, _u8p]),
     "tg_env_show": (ctypes.c_int, [_vp, _vp]),
+    "tg_sp_reset": (ctypes.c_int, [_vp, _vp, _vp]),
+    "tg_sp_batch_rows": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32)]),
+    "tg_sp_batch_obs": (ctypes.c_int, [_vp, _vp, ctypes.c_int32]),
+    "tg_sp_set_eval": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32]),
+    "tg_sp_eval": (ctypes.c_int, [_vp]),
+    "tg_sp_expand_roots": (ctypes.c_int, [_vp]),
+    "tg_sp_begin_move": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    "tg_sp_collect": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
+    "tg_sp_absorb": (ctypes.c_int, [_vp]),
+    "tg_sp_search": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32)]),
+    "tg_sp_root_info": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "tg_sp_draw_uniform": (ctypes.c_int, [_vp, _vp, _vp]),
+    "tg_sp_rng_state": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(TgMt19937)]),
+    "tg_sp_play": (ctypes.c_int, [_vp, _vp, _vp]),
+    "tg_sp_final": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "tg_sp_stats": (ctypes.c_int, [_vp] + [ctypes.POINTER(ctypes.c_uint64)] * 4 + [ctypes.POINTER(ctypes.c_int32)] * 2),
+    "tg_host_mt_seed": (None, [ctypes.POINTER(TgMt19937), ctypes.c_uint32]),
+    "tg_host_mt_next32": (ctypes.c_uint32, [ctypes.POINTER(TgMt19937)]),
+    "tg_host_mt_random_sample": (ctypes.c_double, [ctypes.POINTER(TgMt19937)]),
+    "tg_host_mt_choice_index": (ctypes.c_int32, [ctypes.POINTER(TgMt19937), ctypes.c_int32]),
+    "tg_host_mt_dirichlet": (ctypes.c_int, [ctypes.POINTER(TgMt19937), ctypes.c_double, ctypes.c_int32, _vp]),
 }
 
 

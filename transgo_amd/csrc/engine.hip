@@ -1,4 +1,770 @@
-// engine.hip -- placeholder until the tree/network engine lands (next milestone)
+// engine.hip -- batched WP_MCTS over G concurrent games: tree kernels + the tg_sp_* entry points.
+//
+// One 64-lane workgroup per game in every kernel.  A "wave" of the reference (`WP_MCTS.run`, self_play.py:607-654) is
+// split at the network call into k_collect (selection, leaf stepping, pseudo-expansion, WU-UCT counters, terminal
+// backups, feature encoding straight into the evaluation batch) and k_absorb (counter revert, prior renormalisation,
+// expansion, value backup).  Between the two the batch is evaluated by the network (net.hip) or, for parity tests,
+// by values injected through tg_sp_set_eval.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
 #include "ctx.h"
-extern "C" int tg_engine_create(tg_ctx* ctx) { ctx->err = "engine not built yet"; return TG_ERR_ARG; }
-extern "C" void tg_engine_destroy(tg_ctx*) {}
+#include "engine.h"
+#include "tree_dev.h"
+
+using namespace tg;
+
+namespace {
+
+// ---- device helpers -------------------------------------------------------------------------------------------------------
+
+template <int S> __device__ __forceinline__ NodeRec* arena_of(NodeRec* base, int g, int half, int slots) {
+    return base + ((size_t)g * 2 + half) * (size_t)slots;
+}
+template <int S> __device__ __forceinline__ BlockHdr<S>* hdr_of(NodeRec* arena, int blk) {
+    return reinterpret_cast<BlockHdr<S>*>(arena + blk);
+}
+
+// Allocate and write the block of a node whose position `st` is loaded + analysed in `bw`: header + one fresh child
+// record per legal action (Node_V.expand with prior 0.0, self_play.py:70-77, :634-636).  Returns the block slot or -1.
+template <int S>
+__device__ int make_block(BoardWave<S>& bw, const BoardState<S>& st, NodeRec* arena, int& free_slot, int cap, bool children) {
+    using G = Geo<S>;
+    constexpr int HS = TreeGeo<S>::HS;
+    uint64_t lw[G::NW];
+    int npts = 0;
+    if (children) {
+        legal_words(bw, st, lw);
+#pragma unroll
+        for (int k = 0; k < G::NW; ++k) npts += __popcll(lw[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < G::NW; ++k) lw[k] = 0;
+    }
+    const int nchild = children ? (npts > 0 ? npts : 1) : 0;          // environment.py:121-129: pass only if alone
+    const int blk = free_slot;
+    if (blk + HS + nchild > cap) return -1;
+    free_slot = blk + HS + nchild;
+    const int lane = bw.lane;
+    if (lane == 0) {
+        BlockHdr<S> h;
+        h.st = st; h.nchild = nchild; h.pad[0] = h.pad[1] = h.pad[2] = 0;
+        *hdr_of<S>(arena, blk) = h;
+    }
+    NodeRec r;
+    r.prior = 0.0; r.w = -0.0f; r.var = 0.f; r.n = 0; r.pending = 0; r.block = -1; r.flags = 0; r.term = 0;
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < G::NW; ++k) {
+        if ((lw[k] >> lane) & 1) {
+            int idx = base + __popcll(lw[k] & ((1ull << lane) - 1ull));
+            r.action = (uint16_t)bw.pt[k];
+            arena[blk + HS + idx] = r;
+        }
+        base += __popcll(lw[k]);
+    }
+    if (children && npts == 0 && lane == 0) { r.action = (uint16_t)G::P; arena[blk + HS] = r; }
+    return blk;
+}
+
+// ---- kernels ---------------------------------------------------------------------------------------------------------------
+
+template <int S>
+__global__ __launch_bounds__(64) void k_reset(EngineDev d, const uint8_t* mask) {
+    using G = Geo<S>;
+    __shared__ WaveLds<S> lds;
+    const int g = blockIdx.x;
+    if (mask && !mask[g]) return;
+    BoardWave<S> bw; bw.init(&lds);
+    GameCtl c = d.ctl[g];                                             // cumulative statistics survive a reset
+    c.cur = 0; c.free_slot = 0; c.n_target = 0; c.active = 0; c.n_paths = 0; c.need_eval = 0; c.root_row = 0;
+    c.finished = 0; c.error = 0; c.searching = 0;
+    NodeRec* arena = arena_of<S>(d.arena, g, 0, d.sc.arena_slots);
+    BoardState<S> st; state_reset(st);
+    bw.load_colors(st.bb[0], st.bb[1]);
+    bw.analyze();
+    int free_slot = 1;
+    int blk = make_block(bw, st, arena, free_slot, d.sc.arena_slots, true);
+    int row = 0;
+    if (bw.lane == 0) row = atomicAdd(&d.counters[CNT_ROWS], 1);
+    row = __shfl(row, 0);
+    encode_planes(bw, st, d.rules, d.obs + (size_t)row * d.rules.encode_dim * G::P);
+    if (bw.lane == 0) {
+        NodeRec r;                                                    // Node_V(0), self_play.py:596
+        r.prior = 0.0; r.w = 0.f; r.var = 0.f; r.n = 0; r.pending = 0; r.block = blk; r.action = 0xFFFF; r.flags = 0; r.term = 0;
+        arena[0] = r;
+        c.cur = 0; c.free_slot = free_slot; c.need_eval = 1; c.root_row = row; c.error = blk < 0 ? 1 : 0;
+        d.ctl[g] = c;
+        d.row_game[row] = g;
+    }
+}
+
+// root.expand(action_priors, value) with raw, un-normalised priors (self_play.py:599-605, :864-870)
+template <int S>
+__global__ __launch_bounds__(64) void k_expand_roots(EngineDev d) {
+    constexpr int HS = TreeGeo<S>::HS;
+    const int g = blockIdx.x, lane = lane_id();
+    GameCtl* c = &d.ctl[g];
+    if (!c->need_eval) return;
+    NodeRec* arena = arena_of<S>(d.arena, g, c->cur, d.sc.arena_slots);
+    const int blk = arena[0].block, row = c->root_row;
+    const int nchild = hdr_of<S>(arena, blk)->nchild;
+    const float* pol = d.policy + (size_t)row * d.sc.A;
+    const float val = d.value[row];
+    for (int i = lane; i < nchild; i += 64) {
+        NodeRec* r = &arena[blk + HS + i];
+        r->prior = (double)pol[r->action];
+        r->w = -val;
+        r->flags = F_PRIOR32;
+    }
+    __syncthreads();
+    if (lane == 0) { arena[0].flags |= F_OPEN; c->need_eval = 0; }
+}
+
+// Dirichlet root noise (self_play.py:90-95): prior <- prior*(1-0.25) + noise*0.25, float32*float -> float32, + float64
+template <int S>
+__global__ __launch_bounds__(64) void k_noise(EngineDev d, const double* noise) {
+    constexpr int HS = TreeGeo<S>::HS;
+    const int g = blockIdx.x, lane = lane_id();
+    GameCtl* c = &d.ctl[g];
+    if (c->finished || c->error) return;
+    NodeRec* arena = arena_of<S>(d.arena, g, c->cur, d.sc.arena_slots);
+    const int blk = arena[0].block;
+    const int nchild = hdr_of<S>(arena, blk)->nchild;
+    for (int i = lane; i < nchild; i += 64) {
+        NodeRec* r = &arena[blk + HS + i];
+        double p;
+        if (r->flags & F_PRIOR32) p = (double)((float)r->prior * 0.75f); else p = r->prior * 0.75;
+        r->prior = p + noise[(size_t)g * d.sc.A + i] * 0.25;
+        r->flags &= (uint8_t)~F_PRIOR32;
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(64) void k_begin(EngineDev d, int sims) {
+    const int g = blockIdx.x;
+    if (lane_id() != 0) return;
+    GameCtl* c = &d.ctl[g];
+    NodeRec* arena = arena_of<S>(d.arena, g, c->cur, d.sc.arena_slots);
+    c->n_target = arena[0].n + sims;                                  // self_play.py:662-663
+    c->searching = (c->finished || c->error) ? 0 : 1;
+    c->active = c->searching;
+}
+
+template <int S>
+__global__ __launch_bounds__(64) void k_collect(EngineDev d) {
+    using G = Geo<S>;
+    constexpr int HS = TreeGeo<S>::HS, NPASS = TreeGeo<S>::NPASS;
+    __shared__ WaveLds<S> lds;
+    __shared__ uint32_t mt_scratch[1248];
+    const int g = blockIdx.x, lane = lane_id();
+    GameCtl* c = &d.ctl[g];
+    const SearchCfg& sc = d.sc;
+    if (lane == 0) c->n_paths = 0;
+    if (!c->searching) return;
+    NodeRec* arena = arena_of<S>(d.arena, g, c->cur, sc.arena_slots);
+    if (arena[0].n >= c->n_target) { if (lane == 0) c->active = 0; return; }
+    if (lane == 0) atomicAdd(&d.counters[CNT_ACTIVE], 1);
+    BoardWave<S> bw; bw.init(&lds);
+    WaveRng rng; rng.key = d.rng[g].key; rng.pos = d.rng[g].pos; rng.scratch = mt_scratch; rng.draws = 0;
+    int free_slot = c->free_slot;
+    int* paths = d.path_nodes + (size_t)g * sc.R * sc.maxd;
+    int npaths = 0, err = 0;
+    int leafs[8], rows[8];
+    unsigned long long sims = 0, depth_sum = 0, evals = 0;
+
+    for (int attempt = 0; attempt < 2 * sc.R && npaths < sc.R && !err; ++attempt) {    // self_play.py:616
+        int* path = paths + npaths * sc.maxd;
+        int node = 0, depth = 0;
+        if (lane == 0) path[0] = 0;
+        NodeRec cur = arena[0];
+        int prev = -1;
+        // ---- selection (self_play.py:623-627, :706-725) ----
+        while (cur.flags & F_OPEN) {
+            const int blk = cur.block;
+            const int nchild = hdr_of<S>(arena, blk)->nchild;
+            const double sq = sqrt((double)(cur.n + cur.pending));
+            double scv[NPASS];
+            double best = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < NPASS; ++j) {
+                const int i = j * 64 + lane;
+                scv[j] = -INFINITY;
+                if (i < nchild) { NodeRec ch = arena[blk + HS + i]; scv[j] = puct_score(ch, sq, sc); }
+                best = scv[j] > best ? scv[j] : best;
+            }
+            best = wave_max(best);
+            uint64_t tm[NPASS];
+            int ntie = 0;
+#pragma unroll
+            for (int j = 0; j < NPASS; ++j) { tm[j] = ballot64(scv[j] == best); ntie += __popcll(tm[j]); }
+            int k = (ntie > 1) ? rng.choice_index(ntie) : 0;
+            int idx = 0;
+#pragma unroll
+            for (int j = 0; j < NPASS; ++j) {
+                const int pc = __popcll(tm[j]);
+                if (k >= 0 && k < pc) { idx = j * 64 + nth_set_bit(tm[j], k); k = -1; }
+                else if (k >= 0) k -= pc;
+            }
+            prev = node;
+            node = blk + HS + idx;
+            ++depth;
+            if (depth >= sc.maxd || ntie == 0) { err |= 2; break; }
+            if (lane == 0) path[depth] = node;
+            cur = arena[node];
+        }
+        if (depth == 0) err |= 8;                                      // root must be expanded before searching
+        if (err) break;
+        depth_sum += depth;
+        // ---- leaf ----
+        const int len = depth + 1;
+        if (cur.term) {                                                // cached terminal result
+            const float v = cur.term == 1 ? 1.f : -1.f;
+            __syncthreads();
+            for (int dd = lane; dd < len; dd += 64) backup_node(&arena[path[dd]], ((len - 1 - dd) & 1) ? -v : v);
+            __syncthreads();
+            ++sims;
+            continue;
+        }
+        int row = -1;
+        if (cur.flags & F_PSEUDO) {
+            // same leaf reached twice inside one wave: the reference re-steps and re-expands to the identical result
+            // and evaluates it again (self_play.py:629-646); we reuse the first path's row.
+            for (int q = 0; q < npaths; ++q) if (leafs[q] == node) { row = rows[q]; break; }
+        } else {
+            BoardState<S> st = hdr_of<S>(arena, arena[prev].block)->st;
+            bool ok;
+            const bool done = state_step(bw, st, cur.action, d.rules, /*check=*/false, &ok);   // self_play.py:629
+            if (done) {                                                // self_play.py:638-642
+                const float raw = tromp_taylor(bw, st, nullptr);
+                const int winner = (raw - d.rules.komi > 0.f) ? kBlack : kWhite;              // environment.py:118-119
+                const float v = (st.next_player == winner) ? 1.f : -1.f;
+                if (lane == 0) arena[node].term = (v > 0.f) ? 1 : 2;
+                __syncthreads();
+                for (int dd = lane; dd < len; dd += 64) backup_node(&arena[path[dd]], ((len - 1 - dd) & 1) ? -v : v);
+                __syncthreads();
+                ++sims;
+                continue;
+            }
+            bw.load_colors(st.bb[0], st.bb[1]);
+            bw.analyze();
+            const int blk = make_block(bw, st, arena, free_slot, sc.arena_slots, true);
+            if (blk < 0) { err |= 1; break; }
+            if (lane == 0) row = atomicAdd(&d.counters[CNT_ROWS], 1);
+            row = __shfl(row, 0);
+            encode_planes(bw, st, d.rules, d.obs + (size_t)row * d.rules.encode_dim * G::P);   // self_play.py:798
+            if (lane == 0) {
+                arena[node].block = blk;
+                arena[node].flags |= F_PSEUDO;
+                d.row_game[row] = g;
+            }
+            ++evals;
+        }
+        leafs[npaths] = node; rows[npaths] = row;
+        __syncthreads();
+        for (int dd = lane; dd < len; dd += 64) arena[path[dd]].pending += sc.wu;    // self_play.py:767-770
+        if (lane == 0) { d.path_len[(size_t)g * sc.R + npaths] = len; d.path_row[(size_t)g * sc.R + npaths] = row; }
+        __syncthreads();
+        ++npaths;
+    }
+    if (lane == 0) {
+        c->n_paths = npaths; c->free_slot = free_slot; c->error |= err;
+        c->sims += sims; c->depth_sum += depth_sum; c->evals += evals; c->tie_draws += rng.draws;
+        d.rng[g].pos = rng.pos;
+        if (err) atomicAdd(&d.counters[CNT_ERRORS], 1);
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(64) void k_absorb(EngineDev d) {
+    constexpr int HS = TreeGeo<S>::HS;
+    __shared__ float pol_s[Geo<S>::A + 64];
+    const int g = blockIdx.x, lane = lane_id();
+    GameCtl* c = &d.ctl[g];
+    const SearchCfg& sc = d.sc;
+    const int npaths = c->n_paths;
+    if (npaths == 0) return;
+    NodeRec* arena = arena_of<S>(d.arena, g, c->cur, sc.arena_slots);
+    const int* paths = d.path_nodes + (size_t)g * sc.R * sc.maxd;
+    unsigned long long sims = 0;
+    for (int q = 0; q < npaths; ++q) {                                 // self_play.py:651-654
+        const int* path = paths + q * sc.maxd;
+        const int len = d.path_len[(size_t)g * sc.R + q], row = d.path_row[(size_t)g * sc.R + q];
+        for (int dd = lane; dd < len; dd += 64) arena[path[dd]].pending -= sc.wu;     // self_play.py:772-774
+        __syncthreads();
+        const int leaf = path[len - 1];
+        NodeRec lr = arena[leaf];
+        if (lr.flags & F_OPEN) continue;                               // self_play.py:732-734: simulation dropped
+        const int blk = lr.block;
+        const int nchild = hdr_of<S>(arena, blk)->nchild;
+        const float* pol = d.policy + (size_t)row * sc.A;
+        const float val = d.value[row];
+        for (int i = lane; i < nchild; i += 64) pol_s[i] = pol[arena[blk + HS + i].action];
+        __syncthreads();
+        float scale = pol_s[0];                                        // sum(policy[legal]): sequential float32
+        for (int i = 1; i < nchild; ++i) scale = scale + pol_s[i];     // (0 + p0 == p0 exactly)
+        if (scale > 0.f) {                                             // self_play.py:739-752
+            for (int i = lane; i < nchild; i += 64) {
+                NodeRec* r = &arena[blk + HS + i];
+                r->prior = (double)(pol_s[i] / scale);
+                r->w = -val;
+                r->flags |= F_PRIOR32;
+            }
+        }
+        if (lane == 0) arena[leaf].flags = (uint8_t)((lr.flags & ~F_PSEUDO) | F_OPEN);
+        __syncthreads();
+        for (int dd = lane; dd < len; dd += 64) backup_node(&arena[path[dd]], ((len - 1 - dd) & 1) ? -val : val);
+        __syncthreads();
+        ++sims;
+    }
+    if (lane == 0) { c->n_paths = 0; c->sims += sims; }
+}
+
+template <int S>
+__global__ __launch_bounds__(64) void k_root_info(EngineDev d, int32_t* visits, int32_t* root_n, int32_t* player,
+                                                  int32_t* step, int32_t* nchild_out, float* obs) {
+    using G = Geo<S>;
+    constexpr int HS = TreeGeo<S>::HS;
+    __shared__ WaveLds<S> lds;
+    const int g = blockIdx.x, lane = lane_id();
+    GameCtl* c = &d.ctl[g];
+    NodeRec* arena = arena_of<S>(d.arena, g, c->cur, d.sc.arena_slots);
+    const int blk = arena[0].block;
+    BlockHdr<S>* h = hdr_of<S>(arena, blk);
+    const int nchild = h->nchild;
+    if (visits) {
+        for (int a = lane; a < G::A; a += 64) visits[(size_t)g * G::A + a] = 0;
+        __syncthreads();
+        for (int i = lane; i < nchild; i += 64) { NodeRec r = arena[blk + HS + i]; visits[(size_t)g * G::A + r.action] = r.n; }
+    }
+    if (lane == 0) {
+        if (root_n) root_n[g] = arena[0].n;
+        if (player) player[g] = h->st.next_player;
+        if (step) step[g] = h->st.step_count;
+        if (nchild_out) nchild_out[g] = (c->finished || c->error) ? 0 : nchild;
+    }
+    if (obs) {                                                         // env.encode(root.state), self_play.py:685
+        BoardWave<S> bw; bw.init(&lds);
+        BoardState<S> st = h->st;
+        bw.load_colors(st.bb[0], st.bb[1]);
+        bw.analyze();
+        encode_planes(bw, st, d.rules, obs + (size_t)g * d.rules.encode_dim * G::P);
+    }
+}
+
+// update_with_action (self_play.py:857-872) + tree compaction into the other half arena.
+template <int S>
+__global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions, uint8_t* done_out) {
+    using G = Geo<S>;
+    constexpr int HS = TreeGeo<S>::HS, NPASS = TreeGeo<S>::NPASS;
+    __shared__ WaveLds<S> lds;
+    const int g = blockIdx.x, lane = lane_id();
+    GameCtl* c = &d.ctl[g];
+    if (c->finished || c->error) { if (lane == 0) done_out[g] = c->finished ? 1 : 0; return; }
+    const SearchCfg& sc = d.sc;
+    NodeRec* old = arena_of<S>(d.arena, g, c->cur, sc.arena_slots);
+    NodeRec* nw = arena_of<S>(d.arena, g, c->cur ^ 1, sc.arena_slots);
+    const int a = actions[g];
+    const int rblk = old[0].block;
+    const int nchild = hdr_of<S>(old, rblk)->nchild;
+    int idx = -1;
+#pragma unroll
+    for (int j = 0; j < NPASS; ++j) {
+        const int i = j * 64 + lane;
+        bool hit = i < nchild && old[rblk + HS + i].action == a;
+        uint64_t m = ballot64(hit);
+        if (m && idx < 0) idx = j * 64 + __ffsll((long long)m) - 1;
+    }
+    if (idx < 0) { if (lane == 0) { c->error |= 4; done_out[g] = 0; atomicAdd(&d.counters[CNT_ERRORS], 1); } return; }
+    BoardWave<S> bw; bw.init(&lds);
+    BoardState<S> st = hdr_of<S>(old, rblk)->st;
+    bool ok;
+    const bool done = state_step(bw, st, a, d.rules, /*check=*/false, &ok);      // self_play.py:859
+    NodeRec child = old[rblk + HS + idx];
+    int nfree = 1;
+    if (child.flags & F_OPEN) {
+        // keep the subtree: breadth-first copy, block by block, fixing block pointers as we go
+        auto copy_block = [&](int src) -> int {
+            const int n = HS + hdr_of<S>(old, src)->nchild;
+            const uint4* s4 = reinterpret_cast<const uint4*>(old + src);
+            uint4* d4 = reinterpret_cast<uint4*>(nw + nfree);
+            for (int i = lane; i < 2 * n; i += 64) d4[i] = s4[i];
+            const int at = nfree;
+            nfree += n;
+            return at;
+        };
+        int scan = copy_block(child.block);
+        child.block = scan;
+        __syncthreads();
+        while (scan < nfree) {
+            const int nc = hdr_of<S>(nw, scan)->nchild;
+            for (int j0 = 0; j0 < nc; j0 += 64) {
+                const int i = j0 + lane;
+                int cb = -1;
+                if (i < nc) cb = nw[scan + HS + i].block;
+                uint64_t m = ballot64(cb >= 0);
+                while (m) {
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int src = __shfl(cb, b);
+                    const int at = copy_block(src);
+                    if (lane == b) nw[scan + HS + i].block = at;
+                }
+            }
+            scan += HS + nc;
+            __syncthreads();
+        }
+        if (lane == 0) nw[0] = child;
+    } else {
+        // fresh root: it will be evaluated and expanded with raw priors (self_play.py:861-870).  The reference does
+        // so even when the game just ended; that evaluation has no observable effect and is skipped here.
+        if (!done) { bw.load_colors(st.bb[0], st.bb[1]); bw.analyze(); }
+        const int blk = make_block(bw, st, nw, nfree, sc.arena_slots, !done);
+        child.block = blk; child.term = 0; child.flags &= (uint8_t)~F_PSEUDO;
+        if (lane == 0) nw[0] = child;
+        if (!done) {
+            int row = 0;
+            if (lane == 0) row = atomicAdd(&d.counters[CNT_ROWS], 1);
+            row = __shfl(row, 0);
+            encode_planes(bw, st, d.rules, d.obs + (size_t)row * d.rules.encode_dim * G::P);
+            if (lane == 0) { c->need_eval = 1; c->root_row = row; d.row_game[row] = g; }
+        }
+    }
+    if (lane == 0) {
+        c->cur ^= 1; c->free_slot = nfree; c->finished = done ? 1 : 0; c->searching = 0; c->active = 0;
+        done_out[g] = done ? 1 : 0;
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(64) void k_final(EngineDev d, float* score, float* terr, int32_t* winner) {
+    using G = Geo<S>;
+    __shared__ WaveLds<S> lds;
+    const int g = blockIdx.x, lane = lane_id();
+    GameCtl* c = &d.ctl[g];
+    NodeRec* arena = arena_of<S>(d.arena, g, c->cur, d.sc.arena_slots);
+    BoardWave<S> bw; bw.init(&lds);
+    BoardState<S> st = hdr_of<S>(arena, arena[0].block)->st;
+    uint8_t owner[G::NW];
+    const float raw = tromp_taylor(bw, st, owner);
+    const float sc = raw - d.rules.komi;
+    if (lane == 0) { if (score) score[g] = sc; if (winner) winner[g] = sc > 0.f ? kBlack : kWhite; }
+    if (terr)
+#pragma unroll
+        for (int k = 0; k < G::NW; ++k)
+            if (bw.pt[k] < G::P) terr[(size_t)g * G::P + bw.pt[k]] = owner[k] == 1 ? 1.f : owner[k] == 2 ? -1.f : 0.f;
+}
+
+#define TG_LAUNCH(ctx, kern, grid, ...)                                                                   \
+    do {                                                                                                  \
+        if ((ctx)->S == 9) hipLaunchKernelGGL(kern<9>, dim3(grid), dim3(64), 0, (ctx)->stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern<19>, dim3(grid), dim3(64), 0, (ctx)->stream, __VA_ARGS__);             \
+        TG_HIP(ctx, hipGetLastError());                                                                   \
+    } while (0)
+
+int read_counters(tg_ctx* ctx, int32_t* out) {
+    Engine* e = ctx->eng;
+    TG_HIP(ctx, hipMemcpyAsync(out, e->dev.counters, sizeof(int32_t) * CNT_N, hipMemcpyDeviceToHost, ctx->stream));
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TG_OK;
+}
+int zero_counter(tg_ctx* ctx, int which) {
+    TG_HIP(ctx, hipMemsetAsync(ctx->eng->dev.counters + which, 0, sizeof(int32_t), ctx->stream));
+    return TG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tg_engine_create(tg_ctx* ctx) {
+    const tg_config& cfg = ctx->cfg;
+    if (cfg.parallel_readouts < 1 || cfg.parallel_readouts > 8) TG_FAIL(ctx, TG_ERR_ARG, "parallel_readouts must be 1..8");
+    if (cfg.num_simulation < 1) TG_FAIL(ctx, TG_ERR_ARG, "num_simulation must be >= 1");
+    Engine* e = new Engine();
+    ctx->eng = e;
+    const int G = cfg.n_games, R = cfg.parallel_readouts, A = ctx->A, P = ctx->P, C = cfg.encode_dim;
+    const int HS = ctx->S == 9 ? TreeGeo<9>::HS : TreeGeo<19>::HS;
+    e->G = G; e->R = R; e->rows_cap = G * R;
+    SearchCfg& sc = e->dev.sc;
+    sc.R = R; sc.wu = cfg.wu_loss; sc.c1 = cfg.c_puct1; sc.c2 = cfg.c_puct2;
+    sc.c1f = (float)cfg.c_puct1; sc.c2f = (float)cfg.c_puct2; sc.A = A;
+    sc.maxd = ((cfg.max_step + 2 + 63) / 64) * 64;
+    long long slots = cfg.arena_slots > 0 ? cfg.arena_slots : (3LL * cfg.num_simulation + 256) * (HS + A);
+    if (slots < 4LL * (HS + A) || slots > 0x3fffffffLL) TG_FAIL(ctx, TG_ERR_ARG, "arena_slots out of range");
+    sc.arena_slots = (int)slots;
+    e->dev.rules = ctx->rules;
+    size_t arena_bytes = (size_t)G * 2 * (size_t)slots * sizeof(NodeRec);
+    TG_HIP(ctx, hipMalloc((void**)&e->dev.arena, arena_bytes));
+    TG_HIP(ctx, hipMalloc((void**)&e->dev.ctl, sizeof(GameCtl) * G));
+    TG_HIP(ctx, hipMemsetAsync(e->dev.ctl, 0, sizeof(GameCtl) * G, ctx->stream));
+    TG_HIP(ctx, hipMalloc((void**)&e->dev.rng, sizeof(tg_mt19937) * G));
+    TG_HIP(ctx, hipMalloc((void**)&e->dev.path_nodes, sizeof(int32_t) * (size_t)G * R * sc.maxd));
+    TG_HIP(ctx, hipMalloc((void**)&e->dev.path_len, sizeof(int32_t) * (size_t)G * R));
+    TG_HIP(ctx, hipMalloc((void**)&e->dev.path_row, sizeof(int32_t) * (size_t)G * R));
+    TG_HIP(ctx, hipMalloc((void**)&e->dev.row_game, sizeof(int32_t) * (size_t)e->rows_cap));
+    TG_HIP(ctx, hipMalloc((void**)&e->dev.obs, sizeof(float) * (size_t)e->rows_cap * C * P));
+    TG_HIP(ctx, hipMalloc((void**)&e->dev.policy, sizeof(float) * (size_t)e->rows_cap * A));
+    TG_HIP(ctx, hipMalloc((void**)&e->dev.value, sizeof(float) * (size_t)e->rows_cap));
+    TG_HIP(ctx, hipMalloc((void**)&e->dev.counters, sizeof(int32_t) * CNT_N));
+    TG_HIP(ctx, hipMemsetAsync(e->dev.counters, 0, sizeof(int32_t) * CNT_N, ctx->stream));
+    TG_HIP(ctx, hipMalloc((void**)&e->d_noise, sizeof(double) * (size_t)G * A));
+    TG_HIP(ctx, hipMalloc((void**)&e->d_i32, sizeof(int32_t) * (size_t)G * (A + 8)));
+    TG_HIP(ctx, hipMalloc((void**)&e->d_f32, sizeof(float) * (size_t)G * (C * P + P + 8)));
+    TG_HIP(ctx, hipMalloc((void**)&e->d_u8, (size_t)G * 4));
+    e->h_rng.resize(G);
+    e->h_noise.resize((size_t)G * A);
+    e->h_nchild.resize(G);
+    e->arena_bytes = arena_bytes;
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TG_OK;
+}
+
+void tg_engine_destroy(tg_ctx* ctx) {
+    Engine* e = ctx->eng;
+    if (!e) return;
+    void* ptrs[] = {e->dev.arena, e->dev.ctl, e->dev.rng, e->dev.path_nodes, e->dev.path_len, e->dev.path_row, e->dev.row_game,
+                    e->dev.obs, e->dev.policy, e->dev.value, e->dev.counters, e->d_noise, e->d_i32, e->d_f32, e->d_u8};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    tg_net_destroy(ctx);
+    delete e;
+    ctx->eng = nullptr;
+}
+
+#define NEED_ENGINE(ctx) do { if (!(ctx) || !(ctx)->eng) return TG_ERR_ARG; TG_HIP(ctx, hipSetDevice((ctx)->cfg.device)); } while (0)
+
+int tg_sp_reset(tg_ctx* ctx, const uint32_t* seeds, const uint8_t* mask) {
+    NEED_ENGINE(ctx);
+    if (!seeds) return TG_ERR_ARG;
+    Engine* e = ctx->eng;
+    const int G = e->G;
+    if (e->batch_kind != BATCH_NONE) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_reset: an evaluation batch is pending");
+    if (mask && !e->all_reset) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_reset: the first reset must cover every game (mask = NULL)");
+    // RNG streams are seeded on the host (np.random.seed(seed) per game) and shipped
+    TG_HIP(ctx, hipMemcpyAsync(e->h_rng.data(), e->dev.rng, sizeof(tg_mt19937) * G, hipMemcpyDeviceToHost, ctx->stream));
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int g = 0; g < G; ++g) if (!mask || mask[g]) tg_host_mt_seed(&e->h_rng[g], seeds[g]);
+    TG_HIP(ctx, hipMemcpyAsync(e->dev.rng, e->h_rng.data(), sizeof(tg_mt19937) * G, hipMemcpyHostToDevice, ctx->stream));
+    uint8_t* d_mask = nullptr;
+    if (mask) {
+        TG_HIP(ctx, hipMemcpyAsync(e->d_u8, mask, G, hipMemcpyHostToDevice, ctx->stream));
+        d_mask = e->d_u8;
+    }
+    zero_counter(ctx, CNT_ROWS);
+    TG_LAUNCH(ctx, k_reset, G, e->dev, (const uint8_t*)d_mask);
+    e->batch_kind = BATCH_ROOTS; e->batch_ready = false;
+    if (!mask) e->all_reset = true;
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TG_OK;
+}
+
+int tg_sp_batch_rows(tg_ctx* ctx, int32_t* n_rows) {
+    NEED_ENGINE(ctx);
+    int32_t cnt[CNT_N];
+    int rc = read_counters(ctx, cnt);
+    if (rc) return rc;
+    *n_rows = ctx->eng->batch_kind == BATCH_NONE ? 0 : cnt[CNT_ROWS];
+    return TG_OK;
+}
+
+int tg_sp_batch_obs(tg_ctx* ctx, float* obs, int32_t n_rows) {
+    NEED_ENGINE(ctx);
+    Engine* e = ctx->eng;
+    if (n_rows < 0 || n_rows > e->rows_cap) return TG_ERR_ARG;
+    size_t per = (size_t)ctx->cfg.encode_dim * ctx->P;
+    TG_HIP(ctx, hipMemcpyAsync(obs, e->dev.obs, sizeof(float) * per * n_rows, hipMemcpyDeviceToHost, ctx->stream));
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TG_OK;
+}
+
+int tg_sp_set_eval(tg_ctx* ctx, const float* policy, const float* value, int32_t n_rows) {
+    NEED_ENGINE(ctx);
+    Engine* e = ctx->eng;
+    if (e->batch_kind == BATCH_NONE) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_set_eval: no batch pending");
+    if (n_rows < 0 || n_rows > e->rows_cap) return TG_ERR_ARG;
+    TG_HIP(ctx, hipMemcpyAsync(e->dev.policy, policy, sizeof(float) * (size_t)n_rows * ctx->A, hipMemcpyHostToDevice, ctx->stream));
+    TG_HIP(ctx, hipMemcpyAsync(e->dev.value, value, sizeof(float) * (size_t)n_rows, hipMemcpyHostToDevice, ctx->stream));
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    e->batch_ready = true;
+    return TG_OK;
+}
+
+int tg_sp_eval(tg_ctx* ctx) {
+    NEED_ENGINE(ctx);
+    Engine* e = ctx->eng;
+    if (e->batch_kind == BATCH_NONE) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_eval: no batch pending");
+    int32_t cnt[CNT_N];
+    int rc = read_counters(ctx, cnt);
+    if (rc) return rc;
+    rc = tg_net_forward(ctx, cnt[CNT_ROWS]);
+    if (rc) return rc;
+    e->batch_ready = true;
+    return TG_OK;
+}
+
+int tg_sp_expand_roots(tg_ctx* ctx) {
+    NEED_ENGINE(ctx);
+    Engine* e = ctx->eng;
+    if (e->batch_kind != BATCH_ROOTS) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_expand_roots: no root batch pending");
+    if (!e->batch_ready) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_expand_roots: batch not evaluated");
+    TG_LAUNCH(ctx, k_expand_roots, e->G, e->dev);
+    e->batch_kind = BATCH_NONE; e->batch_ready = false;
+    return TG_OK;
+}
+
+int tg_sp_begin_move(tg_ctx* ctx, int selfplay, int num_simulation) {
+    NEED_ENGINE(ctx);
+    Engine* e = ctx->eng;
+    const int G = e->G, A = ctx->A;
+    if (e->batch_kind != BATCH_NONE) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_begin_move: an evaluation batch is pending");
+    if (num_simulation <= 0) num_simulation = ctx->cfg.num_simulation;
+    if (selfplay) {                                                    // root.dirichlet_prior(), self_play.py:659-660
+        int32_t* d_nchild = e->d_i32;
+        TG_LAUNCH(ctx, k_root_info, G, e->dev, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
+                  d_nchild, (float*)nullptr);
+        TG_HIP(ctx, hipMemcpyAsync(e->h_nchild.data(), d_nchild, sizeof(int32_t) * G, hipMemcpyDeviceToHost, ctx->stream));
+        TG_HIP(ctx, hipMemcpyAsync(e->h_rng.data(), e->dev.rng, sizeof(tg_mt19937) * G, hipMemcpyDeviceToHost, ctx->stream));
+        TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int g = 0; g < G; ++g)
+            if (e->h_nchild[g] > 0) tg_host_mt_dirichlet(&e->h_rng[g], 0.03, e->h_nchild[g], &e->h_noise[(size_t)g * A]);
+        TG_HIP(ctx, hipMemcpyAsync(e->dev.rng, e->h_rng.data(), sizeof(tg_mt19937) * G, hipMemcpyHostToDevice, ctx->stream));
+        TG_HIP(ctx, hipMemcpyAsync(e->d_noise, e->h_noise.data(), sizeof(double) * (size_t)G * A, hipMemcpyHostToDevice, ctx->stream));
+        TG_LAUNCH(ctx, k_noise, G, e->dev, (const double*)e->d_noise);
+    }
+    TG_LAUNCH(ctx, k_begin, G, e->dev, num_simulation);
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TG_OK;
+}
+
+int tg_sp_collect(tg_ctx* ctx, int32_t* n_active, int32_t* n_rows) {
+    NEED_ENGINE(ctx);
+    Engine* e = ctx->eng;
+    if (e->batch_kind != BATCH_NONE) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_collect: an evaluation batch is pending");
+    TG_HIP(ctx, hipMemsetAsync(e->dev.counters, 0, sizeof(int32_t) * 2, ctx->stream));     // CNT_ROWS, CNT_ACTIVE
+    TG_LAUNCH(ctx, k_collect, e->G, e->dev);
+    int32_t cnt[CNT_N];
+    int rc = read_counters(ctx, cnt);
+    if (rc) return rc;
+    if (n_active) *n_active = cnt[CNT_ACTIVE];
+    if (n_rows) *n_rows = cnt[CNT_ROWS];
+    e->batch_kind = BATCH_LEAVES; e->batch_ready = cnt[CNT_ROWS] == 0;
+    e->last_rows = cnt[CNT_ROWS];
+    if (cnt[CNT_ERRORS]) TG_FAIL(ctx, TG_ERR_ARENA, "tree arena / path overflow in at least one game (see tg_sp_game_errors)");
+    return TG_OK;
+}
+
+int tg_sp_absorb(tg_ctx* ctx) {
+    NEED_ENGINE(ctx);
+    Engine* e = ctx->eng;
+    if (e->batch_kind != BATCH_LEAVES) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_absorb: no leaf batch pending");
+    if (!e->batch_ready) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_absorb: batch not evaluated");
+    TG_LAUNCH(ctx, k_absorb, e->G, e->dev);
+    e->batch_kind = BATCH_NONE; e->batch_ready = false;
+    return TG_OK;
+}
+
+int tg_sp_search(tg_ctx* ctx, int32_t* n_waves) {
+    NEED_ENGINE(ctx);
+    int waves = 0;
+    for (;;) {
+        int32_t active = 0, rows = 0;
+        int rc = tg_sp_collect(ctx, &active, &rows);
+        if (rc) return rc;
+        if (rows > 0) { rc = tg_net_forward(ctx, rows); if (rc) return rc; ctx->eng->batch_ready = true; }
+        rc = tg_sp_absorb(ctx);
+        if (rc) return rc;
+        if (active == 0) break;
+        ++waves;
+    }
+    if (n_waves) *n_waves = waves;
+    return TG_OK;
+}
+
+int tg_sp_root_info(tg_ctx* ctx, int32_t* visits, int32_t* root_n, int32_t* player, int32_t* step, float* obs) {
+    NEED_ENGINE(ctx);
+    Engine* e = ctx->eng;
+    const int G = e->G, A = ctx->A, P = ctx->P, C = ctx->cfg.encode_dim;
+    int32_t* d_vis = e->d_i32; int32_t* d_n = d_vis + (size_t)G * A; int32_t* d_pl = d_n + G; int32_t* d_st = d_pl + G;
+    float* d_obs = e->d_f32;
+    TG_LAUNCH(ctx, k_root_info, G, e->dev, visits ? d_vis : nullptr, root_n ? d_n : nullptr, player ? d_pl : nullptr,
+              step ? d_st : nullptr, (int32_t*)nullptr, obs ? d_obs : nullptr);
+    if (visits) TG_HIP(ctx, hipMemcpyAsync(visits, d_vis, sizeof(int32_t) * (size_t)G * A, hipMemcpyDeviceToHost, ctx->stream));
+    if (root_n) TG_HIP(ctx, hipMemcpyAsync(root_n, d_n, sizeof(int32_t) * G, hipMemcpyDeviceToHost, ctx->stream));
+    if (player) TG_HIP(ctx, hipMemcpyAsync(player, d_pl, sizeof(int32_t) * G, hipMemcpyDeviceToHost, ctx->stream));
+    if (step) TG_HIP(ctx, hipMemcpyAsync(step, d_st, sizeof(int32_t) * G, hipMemcpyDeviceToHost, ctx->stream));
+    if (obs) TG_HIP(ctx, hipMemcpyAsync(obs, d_obs, sizeof(float) * (size_t)G * C * P, hipMemcpyDeviceToHost, ctx->stream));
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TG_OK;
+}
+
+int tg_sp_draw_uniform(tg_ctx* ctx, double* u, const uint8_t* mask) {
+    NEED_ENGINE(ctx);
+    Engine* e = ctx->eng;
+    const int G = e->G;
+    TG_HIP(ctx, hipMemcpyAsync(e->h_rng.data(), e->dev.rng, sizeof(tg_mt19937) * G, hipMemcpyDeviceToHost, ctx->stream));
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int g = 0; g < G; ++g) u[g] = (!mask || mask[g]) ? tg_host_mt_random_sample(&e->h_rng[g]) : 0.0;
+    TG_HIP(ctx, hipMemcpyAsync(e->dev.rng, e->h_rng.data(), sizeof(tg_mt19937) * G, hipMemcpyHostToDevice, ctx->stream));
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TG_OK;
+}
+
+int tg_sp_rng_state(tg_ctx* ctx, int game, tg_mt19937* out) {
+    NEED_ENGINE(ctx);
+    if (game < 0 || game >= ctx->eng->G || !out) return TG_ERR_ARG;
+    TG_HIP(ctx, hipMemcpyAsync(out, ctx->eng->dev.rng + game, sizeof(tg_mt19937), hipMemcpyDeviceToHost, ctx->stream));
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TG_OK;
+}
+
+int tg_sp_play(tg_ctx* ctx, const int32_t* actions, uint8_t* done) {
+    NEED_ENGINE(ctx);
+    Engine* e = ctx->eng;
+    const int G = e->G;
+    if (!actions || !done) return TG_ERR_ARG;
+    if (e->batch_kind != BATCH_NONE) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_play: an evaluation batch is pending");
+    int32_t* d_act = e->d_i32;
+    TG_HIP(ctx, hipMemcpyAsync(d_act, actions, sizeof(int32_t) * G, hipMemcpyHostToDevice, ctx->stream));
+    zero_counter(ctx, CNT_ROWS);
+    TG_LAUNCH(ctx, k_play, G, e->dev, (const int32_t*)d_act, e->d_u8);
+    TG_HIP(ctx, hipMemcpyAsync(done, e->d_u8, G, hipMemcpyDeviceToHost, ctx->stream));
+    int32_t cnt[CNT_N];
+    int rc = read_counters(ctx, cnt);
+    if (rc) return rc;
+    e->batch_kind = BATCH_ROOTS; e->batch_ready = cnt[CNT_ROWS] == 0; e->last_rows = cnt[CNT_ROWS];
+    if (cnt[CNT_ERRORS]) TG_FAIL(ctx, TG_ERR_ARENA, "tg_sp_play: action not among the root's children in at least one game");
+    return TG_OK;
+}
+
+int tg_sp_final(tg_ctx* ctx, float* score, float* terr, int32_t* winner) {
+    NEED_ENGINE(ctx);
+    Engine* e = ctx->eng;
+    const int G = e->G, P = ctx->P;
+    float* d_score = e->d_f32; float* d_terr = d_score + G; int32_t* d_w = e->d_i32;
+    TG_LAUNCH(ctx, k_final, G, e->dev, d_score, terr ? d_terr : nullptr, d_w);
+    if (score) TG_HIP(ctx, hipMemcpyAsync(score, d_score, sizeof(float) * G, hipMemcpyDeviceToHost, ctx->stream));
+    if (terr) TG_HIP(ctx, hipMemcpyAsync(terr, d_terr, sizeof(float) * (size_t)G * P, hipMemcpyDeviceToHost, ctx->stream));
+    if (winner) TG_HIP(ctx, hipMemcpyAsync(winner, d_w, sizeof(int32_t) * G, hipMemcpyDeviceToHost, ctx->stream));
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TG_OK;
+}
+
+int tg_sp_stats(tg_ctx* ctx, uint64_t* sims, uint64_t* evals, uint64_t* depth_sum, uint64_t* tie_draws, int32_t* errors,
+                int32_t* max_slots) {
+    NEED_ENGINE(ctx);
+    Engine* e = ctx->eng;
+    std::vector<GameCtl> h(e->G);
+    TG_HIP(ctx, hipMemcpyAsync(h.data(), e->dev.ctl, sizeof(GameCtl) * e->G, hipMemcpyDeviceToHost, ctx->stream));
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t s = 0, ev = 0, ds = 0, td = 0; int32_t er = 0, ms = 0;
+    for (const GameCtl& c : h) {
+        s += c.sims; ev += c.evals; ds += c.depth_sum; td += c.tie_draws;
+        er += c.error ? 1 : 0; ms = c.free_slot > ms ? c.free_slot : ms;
+    }
+    if (sims) *sims = s; if (evals) *evals = ev; if (depth_sum) *depth_sum = ds; if (tie_draws) *tie_draws = td;
+    if (errors) *errors = er; if (max_slots) *max_slots = ms;
+    return TG_OK;
+}
+
+}  // extern "C"

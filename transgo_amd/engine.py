@@ -1,0 +1,142 @@
+"""SelfPlayEngine -- host driver of the batched WP_MCTS engine in libtransgo_hip.so.
+
+Mirrors, for G games at once, the per-game objects of the reference: `WP_MCTS.reset_root / get_action_probs /
+update_with_action` (self_play.py:595-605, :657-687, :857-872).  Tree search, rules and the network run on the GPU;
+this class only sequences the phases and does the one part the reference itself does in NumPy float64 on the host --
+turning visit counts into pi and the sampled move (self_play.py:666-683) -- with the same NumPy calls, so those are
+bit-identical by construction.  The random numbers for it come from the game's own MT19937 stream inside the library.
+"""
+import ctypes
+import math
+
+import numpy as np
+
+from . import _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def temperature(game_step):
+    """Config.epsilon_by_frame (configure.py:75-79)."""
+    return 0.65 + (1.0 - 0.65) * math.exp(-1. * game_step / 10)
+
+
+class SelfPlayEngine:
+    def __init__(self, n_games, board_size=9, num_simulation=210, parallel_readouts=4, c_puct1=3, c_puct2=0.05,
+                 wu_loss=2, komi=7.5, max_step=120, encode_dim=10, net_blocks=6, net_filters=128, arena_slots=0,
+                 device=0, evaluator=None):
+        cfg = _lib.default_config()
+        cfg.board_size, cfg.encode_dim, cfg.max_step, cfg.komi = board_size, encode_dim, max_step, komi
+        cfg.n_games, cfg.num_simulation, cfg.parallel_readouts, cfg.wu_loss = n_games, num_simulation, parallel_readouts, wu_loss
+        cfg.c_puct1, cfg.c_puct2, cfg.arena_slots = c_puct1, c_puct2, arena_slots
+        cfg.net_blocks, cfg.net_filters, cfg.device = net_blocks, net_filters, device
+        self.ctx = _lib.Context(cfg)
+        self.G, self.S, self.P, self.A, self.C = n_games, board_size, board_size ** 2, board_size ** 2 + 1, encode_dim
+        self.num_simulation = num_simulation
+        self.evaluator = evaluator            # None -> network on the GPU; callable(obs)->(policy, value) -> injected
+        self.finished = np.zeros(n_games, bool)
+
+    def close(self):
+        self.ctx.close()
+
+    # ---- evaluation of the pending batch --------------------------------------------------------------------------------
+    def _evaluate(self, rows=None):
+        if self.evaluator is None:
+            self.ctx.call("tg_sp_eval")
+            return
+        if rows is None:
+            n = ctypes.c_int32()
+            self.ctx.call("tg_sp_batch_rows", ctypes.byref(n))
+            rows = n.value
+        if rows == 0:
+            return
+        obs = np.empty((rows, self.C, self.S, self.S), np.float32)
+        self.ctx.call("tg_sp_batch_obs", _ptr(obs), rows)
+        policy, value = self.evaluator(obs)
+        policy = np.ascontiguousarray(policy, np.float32); value = np.ascontiguousarray(value, np.float32).reshape(-1)
+        assert policy.shape == (rows, self.A) and value.shape == (rows,)
+        self.ctx.call("tg_sp_set_eval", _ptr(policy), _ptr(value), rows)
+
+    # ---- reference-shaped operations, G games at a time -------------------------------------------------------------------
+    def reset(self, seeds, mask=None):
+        """reset_root (self_play.py:595-605) + np.random.seed(seed) per game."""
+        seeds = np.ascontiguousarray(seeds, np.uint32)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self.ctx.call("tg_sp_reset", _ptr(seeds), _ptr(m))
+        self._evaluate()
+        self.ctx.call("tg_sp_expand_roots")
+        if mask is None:
+            self.finished[:] = False
+        else:
+            self.finished[np.asarray(mask, bool)] = False
+
+    def search(self, selfplay=True, num_simulation=0):
+        """The search part of get_action_probs (self_play.py:659-664)."""
+        self.ctx.call("tg_sp_begin_move", 1 if selfplay else 0, num_simulation)
+        if self.evaluator is None:
+            w = ctypes.c_int32()
+            self.ctx.call("tg_sp_search", ctypes.byref(w))
+            return w.value
+        waves = 0
+        while True:
+            act, rows = ctypes.c_int32(), ctypes.c_int32()
+            self.ctx.call("tg_sp_collect", ctypes.byref(act), ctypes.byref(rows))
+            self._evaluate(rows.value)
+            self.ctx.call("tg_sp_absorb")
+            if act.value == 0:
+                return waves
+            waves += 1
+
+    def root_info(self, obs=True):
+        vis = np.zeros((self.G, self.A), np.int32)
+        rn = np.zeros(self.G, np.int32); pl = np.zeros(self.G, np.int32); st = np.zeros(self.G, np.int32)
+        ob = np.zeros((self.G, self.C, self.S, self.S), np.float32) if obs else None
+        self.ctx.call("tg_sp_root_info", _ptr(vis), _ptr(rn), _ptr(pl), _ptr(st), _ptr(ob))
+        return vis, rn, pl, st, ob
+
+    def choose_moves(self, visits, steps, selfplay=True):
+        """self_play.py:666-683 per game, in NumPy float64 exactly as the reference writes it.  np.random.choice(A, p)
+        is cdf = p.cumsum(); cdf /= cdf[-1]; cdf.searchsorted(random_sample(), 'right') (NumPy mtrand.pyx) with the
+        uniform drawn from the game's stream."""
+        live = ~self.finished
+        u = np.zeros(self.G, np.float64)
+        self.ctx.call("tg_sp_draw_uniform", _ptr(u), _ptr(live.astype(np.uint8)))
+        actions = np.zeros(self.G, np.int32)
+        pis = np.zeros((self.G, self.A), np.float64)
+        for g in np.flatnonzero(live):
+            counts = np.array([int(c) for c in visits[g]])
+            counts = np.where(counts == 1, 0, counts)
+            pis[g] = counts / np.sum(counts)
+            tau = temperature(int(steps[g])) if selfplay else 0.12
+            powed = np.power(counts, 1.0 / tau)
+            probs = np.array(powed) / np.sum(powed)
+            cdf = probs.cumsum(); cdf /= cdf[-1]
+            actions[g] = cdf.searchsorted(u[g], side="right")
+        return actions, pis
+
+    def play(self, actions):
+        """update_with_action (self_play.py:857-872)."""
+        done = np.zeros(self.G, np.uint8)
+        self.ctx.call("tg_sp_play", _ptr(np.ascontiguousarray(actions, np.int32)), _ptr(done))
+        self._evaluate()
+        self.ctx.call("tg_sp_expand_roots")
+        self.finished = done.astype(bool)
+        return self.finished.copy()
+
+    def final(self):
+        score = np.zeros(self.G, np.float32); terr = np.zeros((self.G, self.P), np.float32); win = np.zeros(self.G, np.int32)
+        self.ctx.call("tg_sp_final", _ptr(score), _ptr(terr), _ptr(win))
+        return score, terr, win
+
+    def rng_state(self, game):
+        s = _lib.TgMt19937()
+        self.ctx.call("tg_sp_rng_state", int(game), ctypes.byref(s))
+        return np.frombuffer(s.key, np.uint32).copy(), int(s.pos)
+
+    def stats(self):
+        v = [ctypes.c_uint64() for _ in range(4)]; e = ctypes.c_int32(); m = ctypes.c_int32()
+        self.ctx.call("tg_sp_stats", *[ctypes.byref(x) for x in v], ctypes.byref(e), ctypes.byref(m))
+        return dict(sims=v[0].value, evals=v[1].value, depth_sum=v[2].value, tie_draws=v[3].value, errors=e.value,
+                    max_slots=m.value)

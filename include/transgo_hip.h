@@ -148,6 +148,20 @@ int tg_sp_final(tg_ctx* ctx, float* score /*[G]*/, float* terr /*[G][S*S]*/, int
 int tg_sp_stats(tg_ctx* ctx, uint64_t* sims, uint64_t* evals, uint64_t* depth_sum, uint64_t* tie_draws, int32_t* errors,
                 int32_t* max_slots);
 
+/* ---- network -------------------------------------------------------------------------------------------------------------
+ * Replaces TransGoNetwork.set_weights / main_prediction (model.py:17-27).  The blob is the BatchNorm-folded, kernel-layout
+ * packing of the model's state_dict produced by transgo_amd/model.py:pack_weights (layout documented there and in
+ * DESIGN.md); tg_net_blob_floats gives its exact length.  Loading again later is the weight refresh of
+ * self_play.py:913.  rows_cap: largest batch tg_net_predict will be asked for (engine contexts size it themselves). */
+size_t tg_net_blob_floats(int board_size, int encode_dim, int filters, int blocks);
+int tg_net_load(tg_ctx* ctx, const float* blob, size_t n_floats, int rows_cap);
+/* main_prediction (model.py:17-20) on host buffers: obs f32[n][C][S][S] -> policy f32[n][A] (softmax), value f32[n]
+ * (tanh), own f32[n][S*S] (tanh; may be NULL). */
+int tg_net_predict(tg_ctx* ctx, const float* obs, int n_rows, float* policy, float* value, float* own);
+/* HIP-event timing of the dominant kernel (3x3 conv F->F) on the launch stream: enable, run, read totals. */
+int tg_prof_enable(tg_ctx* ctx, int on, int max_launches);
+int tg_prof_read(tg_ctx* ctx, double* conv_ms, int64_t* conv_launches, double* conv_flops);
+
 /* ---- 3. host-only NumPy-legacy MT19937 helpers ------------------------------------------------------------------------
  * Same stream as np.random.RandomState: key/pos are get_state()[1] / get_state()[2].  No GPU needed. */
 

@@ -1,0 +1,97 @@
+"""fp32 torch restatement of the policy/value/ownership tower.  TEST INFRASTRUCTURE ONLY (parity oracle for net.hip and
+the CPU baseline's evaluator).  Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may import it.
+
+Built from the reference's building blocks -- CNNBlock (model.py:317-324), pre-activation ResidualBlock identity branch
+(model.py:238-248), tail BN+ReLU (model.py:62,94), value/ownership head (model.py:65-69, :97-102) and policy head
+(model.py:73-76, :107-111) -- with the block count and width as parameters, because BASELINE.json's "N-block x
+F-filter" nets cannot be expressed by the reference's hard-coded 9+3 layout (model.py:49-61).  `attention=True` inserts
+the reference's Self_Attention (model.py:288-315) in the policy head as model.py:72,106 does.
+Pinned against the imported reference modules by tests/test_oracle_net.py (golden: tests/golden/net_blocks.npz).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class ConvBnRelu(nn.Module):                 # CNNBlock, model.py:317-324
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv2d(cin, cout, 3, 1, 1), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class PreActBlock(nn.Module):                # ResidualBlock with input_dim == output_dim, model.py:238-248
+    def __init__(self, f):
+        super().__init__()
+        self.batchnormlize_1 = nn.BatchNorm2d(f)
+        self.conv_1 = nn.Conv2d(f, f, 3, 1, 1)
+        self.batchnormlize_2 = nn.BatchNorm2d(f)
+        self.conv_2 = nn.Conv2d(f, f, 3, 1, 1)
+
+    def forward(self, x):
+        y = self.conv_1(F.relu(self.batchnormlize_1(x)))
+        y = self.conv_2(F.relu(self.batchnormlize_2(y)))
+        return x + y
+
+
+class TowerBody(nn.Module):
+    def __init__(self, board_size, input_dim, filters, blocks):
+        super().__init__()
+        self.S = board_size
+        P = board_size * board_size
+        self.conv1 = ConvBnRelu(input_dim, filters)
+        self.res_blocks = nn.ModuleList([PreActBlock(filters) for _ in range(blocks)])
+        self.bn_res_end = nn.BatchNorm2d(filters)
+        self.conv_val_own = ConvBnRelu(filters, 2)
+        self.fc_val_own = nn.Linear(2 * P, 64)
+        self.fc_val = nn.Linear(64, 1)
+        self.fc_own = nn.Linear(64, P)
+        self.conv_act = ConvBnRelu(filters, 4)
+        self.fc_act = nn.Linear(4 * P, P + 1)
+
+    def forward(self, x):
+        P = self.S * self.S
+        x = self.conv1(x)
+        for b in self.res_blocks:
+            x = b(x)
+        x = F.relu(self.bn_res_end(x))
+        h = F.relu(self.fc_val_own(self.conv_val_own(x).view(-1, 2 * P)))
+        val = torch.tanh(self.fc_val(h))
+        own = torch.tanh(self.fc_own(h))
+        act = torch.softmax(self.fc_act(self.conv_act(x).view(-1, 4 * P)), -1)
+        return act, val, own
+
+
+class TowerNetwork(nn.Module):
+    """Same surface as TransGoNetwork (model.py:11-27)."""
+
+    def __init__(self, board_size=9, input_dim=10, filters=128, blocks=6):
+        super().__init__()
+        self.main_network = TowerBody(board_size, input_dim, filters, blocks)
+
+    def main_prediction(self, state):
+        return self.main_network(state)
+
+    def get_weights(self):
+        return {k: v.cpu() for k, v in self.state_dict().items()}
+
+    def set_weights(self, weights):
+        self.load_state_dict(weights)
+
+
+def seeded_tower(board_size=9, input_dim=10, filters=128, blocks=6, seed=1234):
+    """SURVEY.md §8d synthetic weights: torch default init under manual_seed, BN running_mean ~ N(0, 0.1),
+    running_var ~ U(0.5, 1.5)."""
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    net = TowerNetwork(board_size, input_dim, filters, blocks).eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+                m.weight.copy_(1.0 + 0.1 * torch.randn(m.weight.shape, generator=g))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+    return net

@@ -1,0 +1,65 @@
+"""HIP network forward (net.hip through tg_net_predict) against the fp32 torch oracle tower on real encoded positions.
+Tolerance 1e-3 absolute on policy probabilities, value and ownership (BASELINE.json north_star); observed ~1e-6."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _positions(S, n, seed):
+    from oracle.go_oracle import OracleGoEnv
+    env = OracleGoEnv(board_size=S, max_step=S * S)
+    rng = np.random.RandomState(seed)
+    obs = []
+    while len(obs) < n:
+        s, done = env.reset()
+        while not done and len(obs) < n:
+            la = env.getLegalAction(s)
+            s, done = env.step(s, int(la[rng.randint(len(la))]))
+            if rng.rand() < 0.5:
+                obs.append(env.encode(s))
+    return np.stack(obs)
+
+
+@pytest.mark.parametrize("S,F,NB,n", [(9, 32, 2, 300), (9, 128, 6, 257), (9, 64, 3, 5), (19, 128, 2, 9)])
+def test_tower_matches_torch(S, F, NB, n):
+    import torch
+    from oracle.net import seeded_tower
+    from transgo_amd.model import HipNetwork
+    torch.set_num_threads(4)
+    net = seeded_tower(S, 10, F, NB, seed=1234 + F)
+    x = _positions(S, n, 3)
+    with torch.no_grad():
+        p, v, o = net.main_prediction(torch.from_numpy(x))
+    h = HipNetwork(S, 10, F, NB, rows_cap=128)          # smaller than n: exercises chunking
+    h.set_weights(net.get_weights())
+    hp, hv, ho = h.main_prediction(x)
+    ep, ev, eo = np.abs(hp - p.numpy()).max(), np.abs(hv - v.numpy()).max(), np.abs(ho - o.numpy()).max()
+    print(f"S={S} F={F} N={NB}: max abs err policy {ep:.2e} value {ev:.2e} own {eo:.2e}")
+    assert ep < TOL and ev < TOL and eo < TOL
+    assert np.allclose(hp.sum(1), 1.0, atol=1e-5)
+    # single-row call equals the batched rows (tile boundaries / halo rows do not leak between positions)
+    k = min(7, n - 1)
+    hp1, hv1, _ = h.main_prediction(x[k:k + 1])
+    assert np.array_equal(hp1[0], hp[k]) and np.array_equal(hv1[0], hv[k])
+
+
+def test_engine_with_network_smoke():
+    """Whole loop with the network as evaluator: every game completes its simulations, pi is a distribution."""
+    from oracle.net import seeded_tower
+    from transgo_amd.engine import SelfPlayEngine
+    from transgo_amd import model
+    G, sims = 48, 32
+    eng = SelfPlayEngine(G, num_simulation=sims, net_blocks=2, net_filters=32)
+    model.load_into(eng.ctx, seeded_tower(9, 10, 32, 2).get_weights(), 9, 10, 32, 2)
+    eng.reset(np.arange(G))
+    for m in range(3):
+        eng.search()
+        vis, rn, pl, st, ob = eng.root_info()
+        assert (vis.sum(1) >= sims - 1).all() and (st == m + 1).all()
+        acts, pis = eng.choose_moves(vis, st)
+        assert np.allclose(pis.sum(1), 1.0)
+        eng.play(acts)
+    s = eng.stats()
+    assert s["errors"] == 0 and s["sims"] >= 3 * G * sims

@@ -57,6 +57,11 @@ SIGNATURES = {
     "tg_sp_play": (ctypes.c_int, [_vp, _vp, _vp]),
     "tg_sp_final": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "tg_sp_stats": (ctypes.c_int, [_vp] + [ctypes.POINTER(ctypes.c_uint64)] * 4 + [ctypes.POINTER(ctypes.c_int32)] * 2),
+    "tg_net_blob_floats": (ctypes.c_size_t, [ctypes.c_int] * 4),
+    "tg_net_load": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_int]),
+    "tg_net_predict": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
+    "tg_prof_enable": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    "tg_prof_read": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]),
     "tg_host_mt_seed": (None, [ctypes.POINTER(TgMt19937), ctypes.c_uint32]),
     "tg_host_mt_next32": (ctypes.c_uint32, [ctypes.POINTER(TgMt19937)]),
     "tg_host_mt_random_sample": (ctypes.c_double, [ctypes.POINTER(TgMt19937)]),

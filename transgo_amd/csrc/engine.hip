@@ -532,7 +532,7 @@ void tg_engine_destroy(tg_ctx* ctx) {
     ctx->eng = nullptr;
 }
 
-#define NEED_ENGINE(ctx) do { if (!(ctx) || !(ctx)->eng) return TG_ERR_ARG; TG_HIP(ctx, hipSetDevice((ctx)->cfg.device)); } while (0)
+#define NEED_ENGINE(ctx) do { if (!(ctx) || !(ctx)->eng || (ctx)->eng->G <= 0) return TG_ERR_ARG; TG_HIP(ctx, hipSetDevice((ctx)->cfg.device)); } while (0)
 
 int tg_sp_reset(tg_ctx* ctx, const uint32_t* seeds, const uint8_t* mask) {
     NEED_ENGINE(ctx);

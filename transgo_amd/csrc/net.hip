@@ -1,4 +1,405 @@
-// net.hip -- policy/value network forward (placeholder until the MFMA kernels land)
+// net.hip -- policy/value/ownership network forward for gfx950 (replaces TransGoNetwork.main_prediction,
+// model.py:17-20 -> MainNetwork.forward, model.py:79-114, built from CNNBlock model.py:317-324 and the pre-activation
+// ResidualBlock model.py:238-248; inference only, BatchNorm in eval mode).
+//
+// Tower: stem conv3x3(C->F)+BN+ReLU, N x [BN,ReLU,conv3x3,BN,ReLU,conv3x3,+x], BN+ReLU, then the two heads of
+// model.py:65-76 / :97-111 (value/ownership: conv3x3(F->2)+BN+ReLU, FC(2P->64)+ReLU, FC(64->1) tanh, FC(64->P) tanh;
+// policy: conv3x3(F->4)+BN+ReLU, FC(4P->P+1), softmax).
+//
+// The 3x3 convolutions are the one dense contraction of the whole engine and run on the matrix cores as an implicit
+// GEMM in exact fp32 (v_mfma_f32_16x16x4_f32: a k-ordered fmaf chain, so results stay within 1e-3 of torch fp32):
+//   D[cout][position] += W[tap][cout][cin] * X[position + tap][cin]
+// Activations are position-major / channel-minor (NHWC flattened over the batch: row m = leaf*P + point), so a tile of
+// 128 consecutive rows plus a halo of S+1 rows on each side contains every 3x3 neighbour of its rows regardless of
+// where leaf boundaries fall; taps that leave the board are zeroed in registers from a 9-bit per-row mask instead
+// of materialising padded boards.  BatchNorm is folded on the host (transgo_amd/model.py): BN that follows a conv goes
+// into its weights/bias, BN that precedes one (pre-activation) is applied with ReLU while the tile is staged into LDS.
+#include <cmath>
+#include <vector>
+
 #include "engine.h"
-extern "C" int tg_net_forward(tg_ctx* ctx, int) { ctx->err = "no network weights loaded (tg_net_load)"; return TG_ERR_STATE; }
-extern "C" void tg_net_destroy(tg_ctx*) {}
+
+using namespace tg;
+
+namespace tg {
+
+struct ConvW { const float* w; const float* b; };
+struct BlockW { const float* s1; const float* t1; ConvW c1; ConvW c2; };
+
+struct Net {
+    int F = 0, NB = 0, C = 0, S = 0, P = 0, A = 0;
+    float* blob = nullptr; size_t blob_floats = 0;
+    ConvW stem; std::vector<BlockW> blocks; const float* s_end = nullptr; const float* t_end = nullptr;
+    ConvW head; const float* w_vo = nullptr; const float* b_vo = nullptr; const float* w_v = nullptr; const float* b_v = nullptr;
+    const float* w_o = nullptr; const float* b_o = nullptr; const float* w_a = nullptr; const float* b_a = nullptr;
+    float* x0 = nullptr;   // [rows][P][16] input planes, channel-minor
+    float* bufA = nullptr; float* bufB = nullptr; float* bufH = nullptr;   // [rows][P][F]
+    float* hc = nullptr;   // [rows][P][16] head conv output
+    float* own = nullptr;  // [rows][P]
+    int rows_cap = 0;
+    // profiling of the dominant kernel (3x3 conv F->F) with HIP events on the launch stream
+    bool prof = false; std::vector<hipEvent_t> ev; size_t ev_used = 0; double conv_ms = 0; long conv_launches = 0; double conv_flops = 0;
+};
+
+}  // namespace tg
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int TM = 128;         // output rows (positions) per workgroup
+
+template <int S>
+__global__ __launch_bounds__(256) void k_obs_to_rows(const float* __restrict__ obs, float* __restrict__ x0, int rows, int C) {
+    constexpr int P = S * S;
+    const size_t total = (size_t)rows * P * 16;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i & 15);
+        const size_t m = i >> 4;
+        const int p = (int)(m % P);
+        const size_t r = m / P;
+        x0[i] = c < C ? obs[(r * C + c) * P + p] : 0.f;
+    }
+}
+
+// EPI 0: out = relu(acc + bias)      EPI 1: out = acc + bias + res
+template <int S, int CIN, int COUT, bool PRO, int EPI>
+__global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, float* __restrict__ out,
+                                                 const float* __restrict__ res, const float* __restrict__ Wt,
+                                                 const float* __restrict__ bias, const float* __restrict__ ps,
+                                                 const float* __restrict__ pt, int M) {
+    constexpr int P = S * S, HALO = S + 1;
+    constexpr int CC = CIN < 32 ? CIN : 32;         // input channels staged per pass
+    constexpr int RS = CC + 4;                      // LDS row stride (floats)
+    constexpr int NROW = TM + 2 * HALO;
+    constexpr int CT = COUT / 16;                   // cout tiles, all held by every wave
+    constexpr int C4 = CC / 4;
+    __shared__ float xs[NROW * RS];
+    __shared__ float ws[COUT * RS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * TM;
+
+    unsigned vmask[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int m = m0 + (wave * 2 + t) * 16 + j;
+        unsigned mk = 0;
+        if (m < M) {
+            const int p = m % P, x = p % S, y = p / S;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                if (yy >= 0 && yy < S && xx >= 0 && xx < S) mk |= 1u << tap;
+            }
+        }
+        vmask[t] = mk;
+    }
+    f32x4 acc[CT][2];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) { acc[ct][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ct][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    for (int cc = 0; cc < CIN; cc += CC) {
+        __syncthreads();
+        for (int idx = tid; idx < NROW * C4; idx += 256) {
+            const int r = idx / C4, c4 = idx % C4;
+            const int m = m0 - HALO + r;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (m >= 0 && m < M) {
+                v = *reinterpret_cast<const f32x4*>(in + (size_t)m * CIN + cc + c4 * 4);
+                if (PRO) {
+                    const f32x4 s = *reinterpret_cast<const f32x4*>(ps + cc + c4 * 4);
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(pt + cc + c4 * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { float u = v[e] * s[e] + t[e]; v[e] = u > 0.f ? u : 0.f; }
+                }
+            }
+            *reinterpret_cast<f32x4*>(&xs[r * RS + c4 * 4]) = v;
+        }
+        for (int tap = 0; tap < 9; ++tap) {
+            __syncthreads();
+            for (int idx = tid; idx < COUT * C4; idx += 256) {
+                const int co = idx / C4, c4 = idx % C4;
+                *reinterpret_cast<f32x4*>(&ws[co * RS + c4 * 4]) =
+                    *reinterpret_cast<const f32x4*>(Wt + ((size_t)tap * COUT + co) * CIN + cc + c4 * 4);
+            }
+            __syncthreads();
+            const int toff = (tap / 3 - 1) * S + (tap % 3 - 1);
+#pragma unroll
+            for (int sub = 0; sub < CC / 16; ++sub) {
+                f32x4 b[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int r = (wave * 2 + t) * 16 + j + HALO + toff;
+                    b[t] = *reinterpret_cast<const f32x4*>(&xs[r * RS + sub * 16 + kq * 4]);
+                    if (!((vmask[t] >> tap) & 1)) b[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(&ws[(ct * 16 + j) * RS + sub * 16 + kq * 4]);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[0][s], acc[ct][0], 0, 0, 0);
+                        acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[1][s], acc[ct][1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // D tile: row (lane>>4)*4 + r = cout, column lane&15 = position
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int m = m0 + (wave * 2 + t) * 16 + j;
+        if (m >= M) continue;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int co = ct * 16 + kq * 4;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + co);
+            f32x4 v = acc[ct][t] + bv;
+            if (EPI == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            } else {
+                v = v + *reinterpret_cast<const f32x4*>(res + (size_t)m * COUT + co);
+            }
+            *reinterpret_cast<f32x4*>(out + (size_t)m * COUT + co) = v;
+        }
+    }
+}
+
+// Heads after the shared 3x3 conv (hc[row][p][16]: channels 0-1 value/own, 2-5 policy; BN+ReLU already applied).
+template <int S>
+__global__ __launch_bounds__(256) void k_heads(const float* __restrict__ hc, const float* __restrict__ w_vo,
+                                               const float* __restrict__ b_vo, const float* __restrict__ w_v,
+                                               const float* __restrict__ b_v, const float* __restrict__ w_o,
+                                               const float* __restrict__ b_o, const float* __restrict__ w_a,
+                                               const float* __restrict__ b_a, float* __restrict__ policy,
+                                               float* __restrict__ value, float* __restrict__ own) {
+    constexpr int P = S * S, A = P + 1;
+    __shared__ float hin[6 * P];
+    __shared__ float hid[64];
+    __shared__ float logit[A];
+    __shared__ float red[2];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < 6 * P; i += 256) { const int c = i / P, p = i % P; hin[i] = hc[((size_t)row * P + p) * 16 + c]; }
+    __syncthreads();
+    if (tid < 64) {                                                   // fc_val_own + ReLU (model.py:99)
+        float a = b_vo[tid];
+        for (int i = 0; i < 2 * P; ++i) a = fmaf(hin[i], w_vo[i * 64 + tid], a);
+        hid[tid] = a > 0.f ? a : 0.f;
+    }
+    for (int o = tid; o < A; o += 256) {                              // fc_act (model.py:110)
+        float a = b_a[o];
+        const float* hi = hin + 2 * P;
+        for (int i = 0; i < 4 * P; ++i) a = fmaf(hi[i], w_a[(size_t)i * A + o], a);
+        logit[o] = a;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float a = b_v[0];
+        for (int k = 0; k < 64; ++k) a = fmaf(hid[k], w_v[k], a);
+        value[row] = tanhf(a);                                        // model.py:101
+        float mx = logit[0];
+        for (int o = 1; o < A; ++o) mx = logit[o] > mx ? logit[o] : mx;
+        red[0] = mx;
+    }
+    if (own)
+        for (int o = tid; o < P; o += 256) {                          // fc_own (model.py:102)
+            float a = b_o[o];
+            for (int k = 0; k < 64; ++k) a = fmaf(hid[k], w_o[k * P + o], a);
+            own[(size_t)row * P + o] = tanhf(a);
+        }
+    __syncthreads();
+    const float mx = red[0];
+    for (int o = tid; o < A; o += 256) logit[o] = expf(logit[o] - mx);
+    __syncthreads();
+    if (tid == 0) { float s = 0.f; for (int o = 0; o < A; ++o) s += logit[o]; red[1] = s; }
+    __syncthreads();
+    const float inv = 1.f / red[1];
+    for (int o = tid; o < A; o += 256) policy[(size_t)row * A + o] = logit[o] * inv;    // softmax, model.py:111
+}
+
+struct ProfScope {
+    Net* n; hipStream_t st; bool on;
+    ProfScope(Net* net, hipStream_t s, double flops) : n(net), st(s), on(net->prof && net->ev_used + 2 <= net->ev.size()) {
+        if (on) { (void)hipEventRecord(n->ev[n->ev_used], st); n->conv_flops += flops; n->conv_launches++; }
+    }
+    ~ProfScope() { if (on) { (void)hipEventRecord(n->ev[n->ev_used + 1], st); n->ev_used += 2; } }
+};
+
+template <int S, int F>
+int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, float* value, float* own) {
+    constexpr int P = S * S;
+    hipStream_t st = ctx->stream;
+    const int M = rows * P;
+    const int grid = (M + TM - 1) / TM;
+    const double conv_flops = 2.0 * 9.0 * (double)F * (double)F * (double)M;
+    int g0 = (int)(((size_t)M * 16 + 255) / 256); if (g0 > 65535) g0 = 65535;
+    hipLaunchKernelGGL((k_obs_to_rows<S>), dim3(g0), dim3(256), 0, st, obs, n->x0, rows, n->C);
+    hipLaunchKernelGGL((k_conv3x3<S, 16, F, false, 0>), dim3(grid), dim3(256), 0, st, (const float*)n->x0, n->bufA,
+                       (const float*)nullptr, n->stem.w, n->stem.b, (const float*)nullptr, (const float*)nullptr, M);
+    float* x = n->bufA; float* y = n->bufB;
+    for (const BlockW& b : n->blocks) {
+        { ProfScope ps(n, st, conv_flops);
+          hipLaunchKernelGGL((k_conv3x3<S, F, F, true, 0>), dim3(grid), dim3(256), 0, st, (const float*)x, n->bufH,
+                             (const float*)nullptr, b.c1.w, b.c1.b, b.s1, b.t1, M); }
+        { ProfScope ps(n, st, conv_flops);
+          hipLaunchKernelGGL((k_conv3x3<S, F, F, false, 1>), dim3(grid), dim3(256), 0, st, (const float*)n->bufH, y,
+                             (const float*)x, b.c2.w, b.c2.b, (const float*)nullptr, (const float*)nullptr, M); }
+        float* t = x; x = y; y = t;
+    }
+    hipLaunchKernelGGL((k_conv3x3<S, F, 16, true, 0>), dim3(grid), dim3(256), 0, st, (const float*)x, n->hc,
+                       (const float*)nullptr, n->head.w, n->head.b, n->s_end, n->t_end, M);
+    hipLaunchKernelGGL((k_heads<S>), dim3(rows), dim3(256), 0, st, (const float*)n->hc, n->w_vo, n->b_vo, n->w_v, n->b_v,
+                       n->w_o, n->b_o, n->w_a, n->b_a, policy, value, own);
+    TG_HIP(ctx, hipGetLastError());
+    return TG_OK;
+}
+
+int forward(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, float* value, float* own) {
+    if (rows <= 0) return TG_OK;
+    if (rows > n->rows_cap) TG_FAIL(ctx, TG_ERR_ARG, "network batch larger than the allocated activation buffers");
+#define TG_NET_CASE(SZ, FF) if (n->S == SZ && n->F == FF) return forward_t<SZ, FF>(ctx, n, obs, rows, policy, value, own)
+    TG_NET_CASE(9, 32); TG_NET_CASE(9, 64); TG_NET_CASE(9, 128); TG_NET_CASE(9, 256);
+    TG_NET_CASE(19, 128); TG_NET_CASE(19, 256);
+#undef TG_NET_CASE
+    TG_FAIL(ctx, TG_ERR_ARG, "unsupported (board_size, net_filters): built are 9x{32,64,128,256}, 19x{128,256}");
+}
+
+size_t expected_floats(int S, int C, int F, int NB) {
+    const size_t P = (size_t)S * S, A = P + 1;
+    (void)C;
+    size_t n = 9 * (size_t)F * 16 + F;
+    n += (size_t)NB * (2 * (size_t)F + 2 * (9 * (size_t)F * F + F));
+    n += 2 * (size_t)F;
+    n += 9 * 16 * (size_t)F + 16;
+    n += 2 * P * 64 + 64 + 64 + 1 + 64 * P + P + 4 * P * A + A;
+    return n;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t tg_net_blob_floats(int board_size, int encode_dim, int filters, int blocks) {
+    return expected_floats(board_size, encode_dim, filters, blocks);
+}
+
+int tg_net_load(tg_ctx* ctx, const float* blob, size_t n_floats, int rows_cap) {
+    if (!ctx || !blob) return TG_ERR_ARG;
+    TG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    const int S = ctx->S, C = ctx->cfg.encode_dim, F = ctx->cfg.net_filters, NB = ctx->cfg.net_blocks;
+    if (C > 16) TG_FAIL(ctx, TG_ERR_ARG, "encode_dim > 16 not supported by the stem kernel");
+    if (F % 32 != 0 || NB < 0) TG_FAIL(ctx, TG_ERR_ARG, "net_filters must be a multiple of 32");
+    if (n_floats != expected_floats(S, C, F, NB)) TG_FAIL(ctx, TG_ERR_ARG, "weight blob size does not match (board_size, filters, blocks)");
+    if (!ctx->eng) { ctx->eng = new Engine(); }          // rules-only context + network: a bare evaluator
+    Engine* e = ctx->eng;
+    if (rows_cap <= 0) rows_cap = e->rows_cap > 0 ? e->rows_cap : 256;
+    if (e->rows_cap > rows_cap) rows_cap = e->rows_cap;
+    Net* n = e->net;
+    if (n && (n->rows_cap < rows_cap)) { tg_net_destroy(ctx); n = nullptr; }
+    const size_t P = (size_t)S * S, A = P + 1;
+    if (!n) {
+        n = new Net();
+        e->net = n;
+        n->S = S; n->P = (int)P; n->A = (int)A; n->C = C; n->F = F; n->NB = NB; n->rows_cap = rows_cap;
+        n->blob_floats = n_floats;
+        TG_HIP(ctx, hipMalloc((void**)&n->blob, sizeof(float) * n_floats));
+        const size_t act = sizeof(float) * (size_t)rows_cap * P * F;
+        TG_HIP(ctx, hipMalloc((void**)&n->bufA, act));
+        TG_HIP(ctx, hipMalloc((void**)&n->bufB, act));
+        TG_HIP(ctx, hipMalloc((void**)&n->bufH, act));
+        TG_HIP(ctx, hipMalloc((void**)&n->x0, sizeof(float) * (size_t)rows_cap * P * 16));
+        TG_HIP(ctx, hipMalloc((void**)&n->hc, sizeof(float) * (size_t)rows_cap * P * 16));
+        TG_HIP(ctx, hipMalloc((void**)&n->own, sizeof(float) * (size_t)rows_cap * P));
+        const float* p = n->blob;
+        auto take = [&](size_t k) { const float* q = p; p += k; return q; };
+        n->stem.w = take(9 * (size_t)F * 16); n->stem.b = take(F);
+        n->blocks.resize(NB);
+        for (BlockW& b : n->blocks) {
+            b.s1 = take(F); b.t1 = take(F);
+            b.c1.w = take(9 * (size_t)F * F); b.c1.b = take(F);
+            b.c2.w = take(9 * (size_t)F * F); b.c2.b = take(F);
+        }
+        n->s_end = take(F); n->t_end = take(F);
+        n->head.w = take(9 * 16 * (size_t)F); n->head.b = take(16);
+        n->w_vo = take(2 * P * 64); n->b_vo = take(64); n->w_v = take(64); n->b_v = take(1);
+        n->w_o = take(64 * P); n->b_o = take(P); n->w_a = take(4 * P * A); n->b_a = take(A);
+    }
+    // weight refresh (trainer.py:76-79 -> self_play.py:913) is just this copy
+    TG_HIP(ctx, hipMemcpyAsync(n->blob, blob, sizeof(float) * n_floats, hipMemcpyHostToDevice, ctx->stream));
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TG_OK;
+}
+
+void tg_net_destroy(tg_ctx* ctx) {
+    if (!ctx || !ctx->eng || !ctx->eng->net) return;
+    Net* n = ctx->eng->net;
+    void* ptrs[] = {n->blob, n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (hipEvent_t ev : n->ev) (void)hipEventDestroy(ev);
+    delete n;
+    ctx->eng->net = nullptr;
+}
+
+int tg_net_forward(tg_ctx* ctx, int rows) {
+    Engine* e = ctx->eng;
+    if (!e || !e->net) TG_FAIL(ctx, TG_ERR_STATE, "no network weights loaded (tg_net_load)");
+    return forward(ctx, e->net, e->dev.obs, rows, e->dev.policy, e->dev.value, nullptr);
+}
+
+// main_prediction on host buffers (model.py:17-20): obs f32[n][C][S][S] -> policy f32[n][A], value f32[n], own f32[n][P]
+int tg_net_predict(tg_ctx* ctx, const float* obs, int n_rows, float* policy, float* value, float* own) {
+    if (!ctx || !ctx->eng || !ctx->eng->net) { if (ctx) ctx->err = "no network weights loaded (tg_net_load)"; return TG_ERR_STATE; }
+    TG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    Net* n = ctx->eng->net;
+    const size_t P = n->P, A = n->A, C = n->C;
+    int done = 0;
+    tg::DevBuf& din = ctx->env_f32; tg::DevBuf& dout = ctx->env_in;
+    while (done < n_rows) {
+        const int k = (n_rows - done) < n->rows_cap ? (n_rows - done) : n->rows_cap;
+        if (din.reserve(sizeof(float) * k * C * P) || dout.reserve(sizeof(float) * k * (A + 1)))
+            TG_FAIL(ctx, TG_ERR_HIP, "hipMalloc failed (predict scratch)");
+        float* d_pol = (float*)dout.p; float* d_val = d_pol + (size_t)k * A;
+        TG_HIP(ctx, hipMemcpyAsync(din.p, obs + (size_t)done * C * P, sizeof(float) * k * C * P, hipMemcpyHostToDevice, ctx->stream));
+        int rc = forward(ctx, n, (const float*)din.p, k, d_pol, d_val, own ? n->own : nullptr);
+        if (rc) return rc;
+        TG_HIP(ctx, hipMemcpyAsync(policy + (size_t)done * A, d_pol, sizeof(float) * k * A, hipMemcpyDeviceToHost, ctx->stream));
+        TG_HIP(ctx, hipMemcpyAsync(value + done, d_val, sizeof(float) * k, hipMemcpyDeviceToHost, ctx->stream));
+        if (own) TG_HIP(ctx, hipMemcpyAsync(own + (size_t)done * P, n->own, sizeof(float) * k * P, hipMemcpyDeviceToHost, ctx->stream));
+        TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        done += k;
+    }
+    return TG_OK;
+}
+
+// HIP-event timing of the dominant kernel (3x3 conv F->F), measured on the stream the kernels are launched on.
+int tg_prof_enable(tg_ctx* ctx, int on, int max_launches) {
+    if (!ctx || !ctx->eng || !ctx->eng->net) return TG_ERR_STATE;
+    Net* n = ctx->eng->net;
+    TG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    if (on) {
+        const size_t want = 2 * (size_t)(max_launches > 0 ? max_launches : 4096);
+        while (n->ev.size() < want) { hipEvent_t ev; TG_HIP(ctx, hipEventCreate(&ev)); n->ev.push_back(ev); }
+        n->ev_used = 0; n->conv_ms = 0; n->conv_launches = 0; n->conv_flops = 0;
+    }
+    n->prof = on != 0;
+    return TG_OK;
+}
+
+int tg_prof_read(tg_ctx* ctx, double* conv_ms, int64_t* conv_launches, double* conv_flops) {
+    if (!ctx || !ctx->eng || !ctx->eng->net) return TG_ERR_STATE;
+    Net* n = ctx->eng->net;
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double ms = 0;
+    for (size_t i = 0; i + 1 < n->ev_used; i += 2) {
+        float t = 0; TG_HIP(ctx, hipEventElapsedTime(&t, n->ev[i], n->ev[i + 1])); ms += t;
+    }
+    n->conv_ms += ms; n->ev_used = 0;
+    if (conv_ms) *conv_ms = n->conv_ms;
+    if (conv_launches) *conv_launches = n->conv_launches;
+    if (conv_flops) *conv_flops = n->conv_flops;
+    return TG_OK;
+}
+
+}  // extern "C"

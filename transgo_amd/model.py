@@ -1,0 +1,114 @@
+"""Weights for the HIP network: state_dict -> BatchNorm-folded, kernel-layout float32 blob, and the reference model
+surface (`main_prediction / get_weights / set_weights`, model.py:11-27) on top of libtransgo_hip.so.
+
+Architecture = the tower BASELINE.json parametrises as "N-block x F-filter", assembled from the reference's own building
+blocks (CNNBlock model.py:317-324, pre-activation ResidualBlock model.py:238-248, tail BN model.py:62/94 and the two heads
+model.py:65-76/97-111).  state_dict key names follow MainNetwork's (model.py:49-76), residual blocks numbered
+`res_blocks.{i}`:
+
+    main_network.conv1.conv.0.{weight,bias}            conv3x3 C->F           main_network.conv1.conv.1.*   BatchNorm
+    main_network.res_blocks.{i}.batchnormlize_1.*      BN1 (pre-activation)   ...conv_1.{weight,bias}       conv3x3 F->F
+    main_network.res_blocks.{i}.batchnormlize_2.*      BN2                    ...conv_2.{weight,bias}       conv3x3 F->F
+    main_network.bn_res_end.*                          tail BN
+    main_network.conv_val_own.conv.{0,1}.*             conv3x3 F->2 + BN      main_network.fc_val_own / fc_val / fc_own
+    main_network.conv_act.conv.{0,1}.*                 conv3x3 F->4 + BN      main_network.fc_act
+
+Blob layout (float32, in this order; `t` = ky*3+kx, convs stored [t][cout][cin] so a cout row is contiguous in cin):
+    stem   W[9][F][16] (cin zero-padded to 16, BN folded)      b[F]
+    block  s1[F] t1[F] | W1[9][F][F] (BN2 folded) b1[F] | W2[9][F][F] b2[F]        x N
+    tail   s_end[F] t_end[F]
+    head   W[9][16][F] (cout 0-1 value/own conv, 2-5 policy conv, 6-15 zero; their BNs folded)  b[16]
+    fc     W_vo^T[2P][64] b[64] | w_v[64] b[1] | W_own^T[64][P] b[P] | W_act^T[4P][A] b[A]
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+EPS = 1e-5   # torch.nn.BatchNorm2d default
+
+
+def _np(t):
+    return t.detach().cpu().numpy().astype(np.float64) if hasattr(t, "detach") else np.asarray(t, np.float64)
+
+
+def _bn(sd, prefix):
+    g, b = _np(sd[prefix + ".weight"]), _np(sd[prefix + ".bias"])
+    m, v = _np(sd[prefix + ".running_mean"]), _np(sd[prefix + ".running_var"])
+    s = g / np.sqrt(v + EPS)
+    return s, b - m * s
+
+
+def _conv_t(w):
+    """torch [co][ci][ky][kx] -> [t][co][ci]"""
+    co, ci = w.shape[:2]
+    return np.transpose(w.reshape(co, ci, 9), (2, 0, 1))
+
+
+def pack_weights(sd, board_size, encode_dim, filters, blocks, prefix="main_network."):
+    S, C, F, NB = board_size, encode_dim, filters, blocks
+    P, A = S * S, S * S + 1
+    out = []
+    g = lambda k: _np(sd[prefix + k])
+    # stem: conv + BN folded
+    s, t = _bn(sd, prefix + "conv1.conv.1")
+    w = g("conv1.conv.0.weight") * s[:, None, None, None]
+    b = g("conv1.conv.0.bias") * s + t
+    wt = np.zeros((9, F, 16)); wt[:, :, :C] = _conv_t(w)
+    out += [wt, b]
+    for i in range(NB):
+        pb = f"res_blocks.{i}."
+        s1, t1 = _bn(sd, prefix + pb + "batchnormlize_1")
+        s2, t2 = _bn(sd, prefix + pb + "batchnormlize_2")
+        w1 = g(pb + "conv_1.weight") * s2[:, None, None, None]
+        b1 = g(pb + "conv_1.bias") * s2 + t2
+        out += [s1, t1, _conv_t(w1), b1, _conv_t(g(pb + "conv_2.weight")), g(pb + "conv_2.bias")]
+    se, te = _bn(sd, prefix + "bn_res_end")
+    out += [se, te]
+    wh = np.zeros((9, 16, F)); bh = np.zeros(16)
+    for name, lo, n in (("conv_val_own", 0, 2), ("conv_act", 2, 4)):
+        s, t = _bn(sd, prefix + name + ".conv.1")
+        w = g(name + ".conv.0.weight") * s[:, None, None, None]
+        wh[:, lo:lo + n, :] = _conv_t(w)
+        bh[lo:lo + n] = g(name + ".conv.0.bias") * s + t
+    out += [wh, bh]
+    out += [g("fc_val_own.weight").T, g("fc_val_own.bias"), g("fc_val.weight")[0], g("fc_val.bias"),
+            g("fc_own.weight").T, g("fc_own.bias"), g("fc_act.weight").T, g("fc_act.bias")]
+    blob = np.concatenate([np.ascontiguousarray(a, np.float64).reshape(-1) for a in out]).astype(np.float32)
+    want = _lib.load().tg_net_blob_floats(S, C, F, NB)
+    if blob.size != want:
+        raise ValueError(f"packed {blob.size} floats, library expects {want} for S={S} C={C} F={F} N={NB}")
+    return blob
+
+
+def load_into(ctx, sd, board_size, encode_dim, filters, blocks, rows_cap=0):
+    blob = pack_weights(sd, board_size, encode_dim, filters, blocks)
+    ctx.call("tg_net_load", blob.ctypes.data_as(ctypes.c_void_p), blob.size, rows_cap)
+
+
+class HipNetwork:
+    """TransGoNetwork surface (model.py:11-27) for inference: main_prediction(x) -> (policy, value, own) as NumPy."""
+
+    def __init__(self, board_size=9, encode_dim=10, filters=128, blocks=6, rows_cap=1024, device=0):
+        cfg = _lib.default_config()
+        cfg.board_size, cfg.encode_dim, cfg.net_filters, cfg.net_blocks, cfg.n_games, cfg.device = \
+            board_size, encode_dim, filters, blocks, 0, device
+        self.ctx = _lib.Context(cfg)
+        self.S, self.C, self.F, self.NB, self.rows_cap = board_size, encode_dim, filters, blocks, rows_cap
+        self._weights = None
+
+    def set_weights(self, weights):                      # model.py:26-27
+        self._weights = weights
+        load_into(self.ctx, weights, self.S, self.C, self.F, self.NB, self.rows_cap)
+
+    def get_weights(self):                               # model.py:23-24
+        return self._weights
+
+    def main_prediction(self, x):                        # model.py:17-20
+        x = np.ascontiguousarray(x.detach().cpu().numpy() if hasattr(x, "detach") else x, np.float32)
+        n, P = x.shape[0], self.S * self.S
+        pol = np.empty((n, P + 1), np.float32); val = np.empty((n,), np.float32); own = np.empty((n, P), np.float32)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        self.ctx.call("tg_net_predict", p(x), n, p(pol), p(val), p(own))
+        return pol, val.reshape(n, 1), own

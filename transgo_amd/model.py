@@ -112,3 +112,43 @@ class HipNetwork:
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         self.ctx.call("tg_net_predict", p(x), n, p(pol), p(val), p(own))
         return pol, val.reshape(n, 1), own
+
+
+def random_weights(board_size=9, encode_dim=10, filters=128, blocks=6, seed=1234):
+    """Synthetic random-init weights of the tower (no checkpoint exists offline): PyTorch's default bounds
+    (uniform +-1/sqrt(fan_in) for conv/linear weights and biases), BatchNorm gamma ~ 1+0.1N, beta ~ 0.1N,
+    running_mean ~ 0.1N, running_var ~ U(0.5, 1.5).  Returns a state_dict of float32 NumPy arrays with the key
+    names documented at the top of this file."""
+    rs = np.random.RandomState(seed)
+    S, C, F = board_size, encode_dim, filters
+    P, A = S * S, S * S + 1
+    sd = {}
+
+    def conv(name, cin, cout):
+        b = 1.0 / np.sqrt(cin * 9)
+        sd[name + ".weight"] = rs.uniform(-b, b, (cout, cin, 3, 3)).astype(np.float32)
+        sd[name + ".bias"] = rs.uniform(-b, b, (cout,)).astype(np.float32)
+
+    def lin(name, cin, cout):
+        b = 1.0 / np.sqrt(cin)
+        sd[name + ".weight"] = rs.uniform(-b, b, (cout, cin)).astype(np.float32)
+        sd[name + ".bias"] = rs.uniform(-b, b, (cout,)).astype(np.float32)
+
+    def bn(name, c):
+        sd[name + ".weight"] = (1.0 + 0.1 * rs.randn(c)).astype(np.float32)
+        sd[name + ".bias"] = (0.1 * rs.randn(c)).astype(np.float32)
+        sd[name + ".running_mean"] = (0.1 * rs.randn(c)).astype(np.float32)
+        sd[name + ".running_var"] = rs.uniform(0.5, 1.5, c).astype(np.float32)
+        sd[name + ".num_batches_tracked"] = np.int64(0)
+
+    p = "main_network."
+    conv(p + "conv1.conv.0", C, F); bn(p + "conv1.conv.1", F)
+    for i in range(blocks):
+        q = p + f"res_blocks.{i}."
+        bn(q + "batchnormlize_1", F); conv(q + "conv_1", F, F); bn(q + "batchnormlize_2", F); conv(q + "conv_2", F, F)
+    bn(p + "bn_res_end", F)
+    conv(p + "conv_val_own.conv.0", F, 2); bn(p + "conv_val_own.conv.1", 2)
+    lin(p + "fc_val_own", 2 * P, 64); lin(p + "fc_val", 64, 1); lin(p + "fc_own", 64, P)
+    conv(p + "conv_act.conv.0", F, 4); bn(p + "conv_act.conv.1", 4)
+    lin(p + "fc_act", 4 * P, A)
+    return sd

@@ -1,0 +1,175 @@
+"""SelfPlay -- the reference's self-play actor (self_play.py:881-983) over the batched HIP engine.
+
+`continuous_self_play(shared_storage_worker, mem)` keeps the reference's contract: weights are pulled with
+`get_info("weights")`, every move bumps `set_info("now_play_steps")`, every finished game bumps
+`set_info("now_play_games")` and appends its 8-fold augmented `(obs, pi, z, own)` tuples with
+`mem.append(obs, pi, z, own)` in the reference's order (self_play.py:929-967), so trainer.py consumes the buffer
+unchanged.  The difference is inside: G games advance together on the GPU instead of one game per actor.
+Storage objects may be Ray actors (methods called through `.remote()`) or plain objects.
+"""
+import time
+
+import numpy as np
+
+from .engine import SelfPlayEngine
+from . import model as _model
+
+
+def _call(method, *args):
+    """obj.method(*args), through .remote() when the object is a Ray actor handle."""
+    if hasattr(method, "remote"):
+        import ray
+        return method.remote(*args)
+    return method(*args)
+
+
+def _get(x):
+    try:
+        import ray
+        return ray.get(x) if isinstance(x, ray.ObjectRef) else x
+    except ImportError:
+        return x
+
+
+def game_targets(observations, pis, players, winner, territory, board_size):
+    """z / ownership targets and the 8 symmetries, in the reference's append order (self_play.py:931-965):
+    for i in 1..4: rot90(i), then fliplr of that."""
+    S = board_size
+    players = np.array(players)
+    z = np.zeros(len(players))
+    z[players == winner] = 1
+    z[players != winner] = -1
+    own = np.zeros((len(players), S * S))
+    own[players == 1] = territory
+    own[players != 1] = -1 * territory
+    out = []
+    for ob, pi, zz, ow in zip(observations, pis, z, own):
+        board_p, pass_p = pi[:-1], pi[-1]
+        for i in (1, 2, 3, 4):
+            rp = np.rot90(board_p.reshape(S, S), i)
+            ro = np.array([np.rot90(pl, i) for pl in ob])
+            rw = np.rot90(ow.reshape(S, S), i)
+            out.append((ro, np.append(rp.flatten(), pass_p), zz, rw.flatten()))
+            fo = np.array([np.fliplr(pl) for pl in ro])
+            out.append((fo, np.append(np.fliplr(rp).flatten(), pass_p), zz, np.fliplr(rw).flatten()))
+    return out
+
+
+class GameRecord:
+    __slots__ = ("observations", "pis", "visits", "players", "winner", "territory", "score", "seed")
+
+    def __init__(self, seed):
+        self.observations, self.pis, self.visits, self.players = [], [], [], []
+        self.winner, self.territory, self.score, self.seed = None, None, None, seed
+
+
+class BatchedSelfPlay:
+    """G concurrent self-play games in lock step (one engine, one GPU)."""
+
+    def __init__(self, config, n_games, device=0, rank=0, world=1, evaluator=None, keep_obs=True, arena_slots=0):
+        self.config, self.G, self.rank, self.world = config, n_games, rank, world
+        self.S = config.board_size
+        self.filters = getattr(config, "num_features", 128)
+        self.blocks = getattr(config, "num_blocks", 6)
+        self.engine = SelfPlayEngine(
+            n_games, board_size=self.S, num_simulation=config.num_simulation,
+            parallel_readouts=config.parallel_readouts, c_puct1=config.c_puct1, c_puct2=config.c_puct2,
+            wu_loss=config.wu_loss, komi=config.komi, max_step=config.max_step,
+            encode_dim=config.encode_state_channels, net_blocks=self.blocks, net_filters=self.filters,
+            arena_slots=arena_slots, device=device, evaluator=evaluator)
+        self.keep_obs = keep_obs
+        self.games_started = np.zeros(n_games, np.int64)
+        self.records = [None] * n_games
+        self.moves_played = 0
+        self.games_finished = 0
+        self._started = False
+
+    def seed_of(self, g):
+        """Game seeds s = 1000*rank + g for the first game of a slot, then a fixed stride per restart."""
+        return (1000 * self.rank + g + 1000003 * int(self.games_started[g]) * max(1, self.world)) % (2 ** 32)
+
+    def set_weights(self, state_dict):
+        _model.load_into(self.engine.ctx, state_dict, self.S, self.config.encode_state_channels, self.filters, self.blocks)
+
+    def _reset(self, mask=None):
+        idx = range(self.G) if mask is None else np.flatnonzero(mask)
+        seeds = np.zeros(self.G, np.uint32)
+        for g in idx:
+            seeds[g] = self.seed_of(g)
+            self.records[g] = GameRecord(int(seeds[g]))
+            self.games_started[g] += 1
+        self.engine.reset(seeds, mask)
+
+    def start(self):
+        self._reset(None)
+        self._started = True
+
+    def step(self, selfplay=True):
+        """One move of every game: get_action_probs + update_with_action (self_play.py:917-926).  Returns the records
+        of the games that ended with this move; their slots are restarted."""
+        if not self._started:
+            self.start()
+        eng = self.engine
+        eng.search(selfplay)
+        vis, rn, players, steps, obs = eng.root_info(obs=self.keep_obs)
+        actions, pis = eng.choose_moves(vis, steps, selfplay)
+        for g in range(self.G):
+            r = self.records[g]
+            if self.keep_obs:
+                r.observations.append(obs[g].copy())
+            r.pis.append(pis[g]); r.visits.append(vis[g].copy()); r.players.append(int(players[g]))
+        done = eng.play(actions)
+        self.moves_played += self.G
+        finished = []
+        if done.any():
+            score, terr, win = eng.final()
+            for g in np.flatnonzero(done):
+                r = self.records[g]
+                r.winner, r.territory, r.score = int(win[g]), terr[g].copy(), float(score[g])
+                finished.append(r)
+            self.games_finished += len(finished)
+            self._reset(done)
+        return finished
+
+    def targets(self, record):
+        return game_targets(record.observations, record.pis, record.players, record.winner, record.territory, self.S)
+
+
+class SelfPlay:
+    """Reference actor surface (self_play.py:881-983)."""
+
+    def __init__(self, config, n_games=None, device=0, rank=0, world=1):
+        self.config = config
+        self.n_games = n_games or getattr(config, "concurrent_games", 1024)
+        self.worker = BatchedSelfPlay(config, self.n_games, device=device, rank=rank, world=world)
+        self._weights_version = None
+
+    def _refresh_weights(self, shared_storage_worker):
+        w = _get(_call(shared_storage_worker.get_info, "weights"))              # self_play.py:913
+        if w is not None and id(w) != self._weights_version:
+            self.worker.set_weights(w)
+            self._weights_version = id(w)
+
+    def continuous_self_play(self, shared_storage_worker, mem, max_moves=None):
+        moves = 0
+        while max_moves is None or moves < max_moves:
+            start = time.time()
+            self._refresh_weights(shared_storage_worker)
+            finished = self.worker.step()
+            for _ in range(self.worker.G):
+                _call(shared_storage_worker.set_info, "now_play_steps")           # self_play.py:928
+            for rec in finished:
+                for tup in self.worker.targets(rec):
+                    _call(mem.append, *tup)                                       # self_play.py:956, :965
+                _call(shared_storage_worker.set_info, "now_play_games")           # self_play.py:967
+            moves += 1
+            while (finished and                                                   # self_play.py:970-980
+                   _get(_call(shared_storage_worker.get_info, "now_train_steps"))
+                   / max(1, _get(_call(shared_storage_worker.get_info, "now_play_steps")))
+                   < _get(_call(shared_storage_worker.get_info, "train_play_ratio"))
+                   and _get(_call(shared_storage_worker.get_info, "adjust_train_play_ratio"))
+                   and _get(_call(shared_storage_worker.get_info, "now_play_games"))
+                   < _get(_call(shared_storage_worker.get_info, "game_total_num"))):
+                time.sleep(0.5)
+            if finished:
+                print("run time:%.4fs" % (time.time() - start))

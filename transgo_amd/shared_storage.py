@@ -1,0 +1,32 @@
+"""SharedStorage with the reference's interface and key semantics (shared_storage.py:6-43): get_info(key | list),
+set_info(key, value) / set_info(dict) / the increment form set_info("now_play_steps" | "now_play_games") that also
+drives the learning-rate and train/play-ratio schedules (configure.py:90-103)."""
+import copy
+
+
+class SharedStorage:
+    def __init__(self, checkpoint, config):
+        self.config = config
+        self.current_checkpoint = copy.deepcopy(checkpoint)
+
+    def get_info(self, keys):                                       # shared_storage.py:13-19
+        if isinstance(keys, str):
+            return self.current_checkpoint[keys]
+        if isinstance(keys, list):
+            return {k: self.current_checkpoint[k] for k in keys}
+        raise TypeError
+
+    def set_info(self, keys, values=None):                          # shared_storage.py:21-43
+        cp = self.current_checkpoint
+        if keys == "now_play_steps" or keys == "now_play_games":
+            cp[keys] += 1
+        elif isinstance(keys, str) and values is not None:
+            cp[keys] = values
+        elif isinstance(keys, dict):
+            cp.update(keys)
+        else:
+            raise TypeError(keys)
+        if keys == "now_play_games" and cp.get("adjust_lr") is True:
+            cp["learn_rate"] = self.config.ad_lr(cp["now_play_games"], cp["learn_rate"])
+        if keys == "now_play_steps" and cp.get("adjust_train_play_ratio") is True and cp["now_play_games"] > 0:
+            cp["train_play_ratio"] = self.config.ad_train_play_ratio(cp["now_play_steps"], cp["train_play_ratio"])

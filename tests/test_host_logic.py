@@ -1,0 +1,131 @@
+"""Host-side pieces of the hot path that need no GPU: target generation + augmentation order against tuples recorded
+from the reference's own continuous_self_play (tests/golden/targets_game.npz), weight packing, storage interfaces, and the
+2-rank gather over gloo."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from transgo_amd import model
+from transgo_amd.configure import Config
+from transgo_amd.replay_buffer import ReplayMemory_Random
+from transgo_amd.self_play import GameRecord, game_targets
+from transgo_amd.shared_storage import SharedStorage
+
+
+def _load(golden_dir, name):
+    with np.load(os.path.join(golden_dir, name)) as z:
+        return {k: z[k] for k in z.files}
+
+
+def test_targets_match_reference_appends(golden_dir):
+    b = _load(golden_dir, "targets_game.npz")
+    n = len(b["z"]) // 8
+    # un-augmented material = the 8th tuple of each position (rot90 k=4 is the identity)
+    obs = [b["obs"][8 * i + 6] for i in range(n)]; pis = [b["pi"][8 * i + 6] for i in range(n)]
+    players = [1 + (i % 2) for i in range(n)]
+    z0 = b["z"][6]; winner = 1 if z0 == 1 else 2
+    terr = b["own"][6]                                   # position 0 is black to move: own = territory
+    out = game_targets(obs, pis, players, winner, terr, 9)
+    assert len(out) == 8 * n
+    for i, (o, p, z, w) in enumerate(out):
+        assert o.dtype == np.float32 and o.shape == (10, 9, 9) and p.dtype == np.float64 and w.dtype == np.float64
+        assert (o == b["obs"][i]).all() and (p == b["pi"][i]).all() and z == b["z"][i] and (w == b["own"][i]).all(), i
+
+
+def test_targets_equal_oracle_restatement():
+    from oracle.go_oracle import OracleGoEnv
+    from oracle.wp_mcts import targets_for_game
+    env = OracleGoEnv(max_step=16)
+    rng = np.random.RandomState(3)
+    s, done = env.reset()
+    obs, pis, players = [], [], []
+    while not done:
+        la = env.getLegalAction(s)
+        obs.append(env.encode(s)); players.append(env.getPlayer(s))
+        c = rng.randint(0, 5, 82).astype(np.float64); c[la[0]] += 1; pis.append(c / c.sum())
+        s, done = env.step(s, int(la[rng.randint(len(la))]))
+    ref = targets_for_game(env, s, obs, pis, players)
+    _, terr = env.getScoreAndTerritory(s)
+    mine = game_targets(obs, pis, players, env.getWinner(s), terr, 9)
+    assert len(ref) == len(mine) == 8 * len(obs)
+    for a, b in zip(ref, mine):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_pack_weights_layout_roundtrip():
+    sd = model.random_weights(9, 10, 32, 2, seed=3)
+    blob = model.pack_weights(sd, 9, 10, 32, 2)
+    assert blob.dtype == np.float32 and blob.size == 9 * 32 * 16 + 32 + 2 * (64 + 2 * (9 * 32 * 32 + 32)) + 64 + 9 * 16 * 32 + 16 \
+        + 162 * 64 + 64 + 64 + 1 + 64 * 81 + 81 + 324 * 82 + 82
+    # stem: folded BN, [tap][cout][cin16]
+    s = sd["main_network.conv1.conv.1.weight"] / np.sqrt(sd["main_network.conv1.conv.1.running_var"] + 1e-5)
+    w = sd["main_network.conv1.conv.0.weight"]
+    assert np.allclose(blob[(4 * 32 + 5) * 16 + 3], w[5, 3, 1, 1] * s[5], rtol=1e-6)
+    assert blob[(4 * 32 + 5) * 16 + 12] == 0
+
+
+def test_storage_interfaces():
+    cfg = Config(buffer_size=64)
+    mem = ReplayMemory_Random(cfg)
+    for i in range(70):
+        mem.append(np.full((10, 9, 9), i, np.float32), np.full(82, 1 / 82), float(i % 2), np.zeros(81))
+    assert mem.info() == {"capacity": 64, "index": 6, "full": True}
+    batch = mem.sample(16)
+    s, p, z, o = map(np.stack, zip(*batch))              # trainer.py:49
+    assert s.shape == (16, 10, 9, 9) and p.shape == (16, 82) and z.shape == (16,) and o.shape == (16, 81)
+    st = SharedStorage({"weights": None, "now_play_steps": 0, "now_play_games": 0, "learn_rate": 6.5e-5,
+                        "adjust_lr": True, "train_play_ratio": 0.075, "adjust_train_play_ratio": True}, cfg)
+    st.set_info("now_play_games")
+    for _ in range(6):
+        st.set_info("now_play_steps")
+    assert st.get_info("now_play_steps") == 6 and st.get_info(["now_play_games"]) == {"now_play_games": 1}
+    assert st.get_info("train_play_ratio") == (0.075 * 100000 + 1) / 100000     # configure.py:97-103
+    st.set_info({"weights": 1}); st.set_info("learn_rate", 1e-3)
+    assert st.get_info("weights") == 1 and st.get_info("learn_rate") == 1e-3
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _gather_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from transgo_amd.distributed import broadcast_weights, gather_records
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    rng = np.random.RandomState(rank)
+    recs = []
+    for k in range(rank + 1):                            # rank 0: 1 game, rank 1: 2 games (ragged)
+        r = GameRecord(100 * rank + k)
+        for m in range(3 + k):
+            r.observations.append((rng.rand(10, 9, 9) < 0.3).astype(np.float32))
+            v = rng.randint(0, 9, 82).astype(np.int32); v[5] = 7; r.visits.append(v)
+            c = np.where(v == 1, 0, v); r.pis.append(c / c.sum()); r.players.append(1 + m % 2)
+        r.winner = 1 + rank % 2; r.territory = rng.randint(-1, 2, 81).astype(np.float32)
+        recs.append(r)
+    got = gather_records(recs, 9, 10, dst=0)
+    empty = gather_records([], 9, 10, dst=0)             # nothing finished anywhere: no payload exchange
+    blob = np.arange(10, dtype=np.float32) * (rank + 1)
+    blob = broadcast_weights(blob, src=0)
+    out = [(len(g.players), g.winner, float(np.sum(g.territory)), float(sum(p.sum() for p in g.pis)),
+            float(sum(o.sum() for o in g.observations))) for g in got]
+    mine = [(len(g.players), g.winner, float(np.sum(g.territory)), float(sum(p.sum() for p in g.pis)),
+             float(sum(o.sum() for o in g.observations))) for g in recs]
+    q.put((rank, out, mine, len(empty), blob.tolist()))
+    dist.destroy_process_group()
+
+
+def test_gather_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(60) for p in ps]
+    (r0, out0, mine0, e0, b0), (r1, out1, mine1, e1, b1) = res
+    assert out1 == [] and e0 == 0 and e1 == 0
+    assert out0 == mine0 + mine1                          # rank order, exact payloads (pi recomputed from counts)
+    assert b0 == b1 == list(np.arange(10, dtype=np.float32))

@@ -66,7 +66,8 @@ class GameRecord:
 class BatchedSelfPlay:
     """G concurrent self-play games in lock step (one engine, one GPU)."""
 
-    def __init__(self, config, n_games, device=0, rank=0, world=1, evaluator=None, keep_obs=True, arena_slots=0):
+    def __init__(self, config, n_games, device=0, rank=0, world=1, evaluator=None, keep_obs=True, arena_slots=0,
+                 seed_fn=None):
         self.config, self.G, self.rank, self.world = config, n_games, rank, world
         self.S = config.board_size
         self.filters = getattr(config, "num_features", 128)
@@ -78,6 +79,7 @@ class BatchedSelfPlay:
             encode_dim=config.encode_state_channels, net_blocks=self.blocks, net_filters=self.filters,
             arena_slots=arena_slots, device=device, evaluator=evaluator)
         self.keep_obs = keep_obs
+        self.seed_fn = seed_fn
         self.games_started = np.zeros(n_games, np.int64)
         self.records = [None] * n_games
         self.moves_played = 0
@@ -86,6 +88,8 @@ class BatchedSelfPlay:
 
     def seed_of(self, g):
         """Game seeds s = 1000*rank + g for the first game of a slot, then a fixed stride per restart."""
+        if self.seed_fn is not None:
+            return int(self.seed_fn(g, int(self.games_started[g]))) % (2 ** 32)
         return (1000 * self.rank + g + 1000003 * int(self.games_started[g]) * max(1, self.world)) % (2 ** 32)
 
     def set_weights(self, state_dict):

@@ -129,3 +129,24 @@ def test_gather_two_ranks_gloo():
     assert out1 == [] and e0 == 0 and e1 == 0
     assert out0 == mine0 + mine1                          # rank order, exact payloads (pi recomputed from counts)
     assert b0 == b1 == list(np.arange(10, dtype=np.float32))
+
+
+def test_vectorised_move_selection_equals_per_game_form():
+    """transgo_amd.engine.choose_moves_batch == the literal self_play.py:666-683 computation, row by row, bit for bit."""
+    from transgo_amd.engine import choose_moves_batch, choose_moves_reference
+    rng = np.random.RandomState(0)
+    G, A = 3000, 82
+    visits = np.zeros((G, A), np.int32)
+    for g in range(G):
+        k = rng.randint(2, 40)
+        a = rng.choice(A, k, replace=False)
+        visits[g, a] = rng.multinomial(rng.randint(30, 900), rng.dirichlet([0.3] * k)) + rng.randint(0, 3, k)
+        visits[g, a[0]] += 2
+    steps = rng.randint(1, 121, G).astype(np.int32)
+    u = rng.random_sample(G)
+    u[:5] = [0.0, 1.0 - 2 ** -53, 0.5, 0.25, 0.75]
+    live = rng.rand(G) < 0.9
+    for selfplay in (True, False):
+        a1, p1 = choose_moves_reference(visits, steps, u, live, selfplay)
+        a2, p2 = choose_moves_batch(visits, steps, u, live, selfplay)
+        assert np.array_equal(a1, a2) and np.array_equal(p1, p2)

@@ -99,31 +99,71 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, f
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) { acc[ct][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ct][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    for (int cc = 0; cc < CIN; cc += CC) {
-        __syncthreads();
-        for (int idx = tid; idx < NROW * C4; idx += 256) {
-            const int r = idx / C4, c4 = idx % C4;
-            const int m = m0 - HALO + r;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (m >= 0 && m < M) {
-                v = *reinterpret_cast<const f32x4*>(in + (size_t)m * CIN + cc + c4 * 4);
-                if (PRO) {
-                    const f32x4 s = *reinterpret_cast<const f32x4*>(ps + cc + c4 * 4);
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(pt + cc + c4 * 4);
+    // Software pipeline: the global loads of stage s+1 (one tap's weights; every 9th stage also the next 32-channel
+    // slice of the activation tile) are issued before the MFMA block of stage s and land in registers while it runs;
+    // they are written to LDS after the barrier that ends it.
+    constexpr int WL = (COUT * C4 + 255) / 256;
+    constexpr int XL = (NROW * C4 + 255) / 256;
+    f32x4 wreg[WL], xreg[XL];
+    auto load_w = [&](int cc, int tap) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { float u = v[e] * s[e] + t[e]; v[e] = u > 0.f ? u : 0.f; }
-                }
+        for (int i = 0; i < WL; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < COUT * C4) {
+                const int co = idx / C4, c4 = idx % C4;
+                wreg[i] = *reinterpret_cast<const f32x4*>(Wt + ((size_t)tap * COUT + co) * CIN + cc + c4 * 4);
             }
-            *reinterpret_cast<f32x4*>(&xs[r * RS + c4 * 4]) = v;
         }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < WL; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < COUT * C4) { const int co = idx / C4, c4 = idx % C4; *reinterpret_cast<f32x4*>(&ws[co * RS + c4 * 4]) = wreg[i]; }
+        }
+    };
+    auto load_x = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+            const int idx = tid + i * 256;
+            xreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (idx < NROW * C4) {
+                const int r = idx / C4, c4 = idx % C4;
+                const int m = m0 - HALO + r;
+                if (m >= 0 && m < M) xreg[i] = *reinterpret_cast<const f32x4*>(in + (size_t)m * CIN + cc + c4 * 4);
+            }
+        }
+    };
+    auto store_x = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < NROW * C4) {
+                const int r = idx / C4, c4 = idx % C4;
+                f32x4 v = xreg[i];
+                if (PRO) {
+                    const int m = m0 - HALO + r;
+                    if (m >= 0 && m < M) {             // the zero rows outside the batch stay zero (padding is post-activation)
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(ps + cc + c4 * 4);
+                        const f32x4 sh = *reinterpret_cast<const f32x4*>(pt + cc + c4 * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { float u = v[e] * sc[e] + sh[e]; v[e] = u > 0.f ? u : 0.f; }
+                    }
+                }
+                *reinterpret_cast<f32x4*>(&xs[r * RS + c4 * 4]) = v;
+            }
+        }
+    };
+    load_x(0);
+    load_w(0, 0);
+    for (int cc = 0; cc < CIN; cc += CC) {
         for (int tap = 0; tap < 9; ++tap) {
             __syncthreads();
-            for (int idx = tid; idx < COUT * C4; idx += 256) {
-                const int co = idx / C4, c4 = idx % C4;
-                *reinterpret_cast<f32x4*>(&ws[co * RS + c4 * 4]) =
-                    *reinterpret_cast<const f32x4*>(Wt + ((size_t)tap * COUT + co) * CIN + cc + c4 * 4);
-            }
+            if (tap == 0) store_x(cc);
+            store_w();
             __syncthreads();
+            if (tap < 8) load_w(cc, tap + 1);
+            else if (cc + CC < CIN) { load_w(cc + CC, 0); load_x(cc + CC); }
             const int toff = (tap / 3 - 1) * S + (tap % 3 - 1);
 #pragma unroll
             for (int sub = 0; sub < CC / 16; ++sub) {

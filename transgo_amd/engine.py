@@ -23,6 +23,42 @@ def temperature(game_step):
     return 0.65 + (1.0 - 0.65) * math.exp(-1. * game_step / 10)
 
 
+def choose_moves_reference(visits, steps, u, live, selfplay=True):
+    """Literal per-game form of self_play.py:666-683 (the definition choose_moves_batch is tested against)."""
+    G, A = visits.shape
+    actions = np.zeros(G, np.int32)
+    pis = np.zeros((G, A), np.float64)
+    for g in np.flatnonzero(live):
+        counts = np.array([int(c) for c in visits[g]])
+        counts = np.where(counts == 1, 0, counts)
+        pis[g] = counts / np.sum(counts)
+        tau = temperature(int(steps[g])) if selfplay else 0.12
+        powed = np.power(counts, 1.0 / tau)
+        probs = np.array(powed) / np.sum(powed)
+        cdf = probs.cumsum(); cdf /= cdf[-1]
+        actions[g] = cdf.searchsorted(u[g], side="right")
+    return actions, pis
+
+
+def choose_moves_batch(visits, steps, u, live, selfplay=True):
+    G, A = visits.shape
+    actions = np.zeros(G, np.int32)
+    pis = np.zeros((G, A), np.float64)
+    idx = np.flatnonzero(live)
+    if len(idx) == 0:
+        return actions, pis
+    counts = visits[idx].astype(np.int64)
+    counts = np.where(counts == 1, 0, counts)
+    pis[idx] = counts / np.sum(counts, axis=1)[:, None]
+    inv_tau = np.array([1.0 / (temperature(int(s)) if selfplay else 0.12) for s in steps[idx]])
+    powed = np.power(counts, inv_tau[:, None])
+    probs = powed / np.sum(powed, axis=1)[:, None]
+    cdf = np.cumsum(probs, axis=1)
+    cdf /= cdf[:, -1][:, None]
+    actions[idx] = (cdf <= u[idx][:, None]).sum(axis=1)          # searchsorted(u, 'right') on a non-decreasing row
+    return actions, pis
+
+
 class SelfPlayEngine:
     def __init__(self, n_games, board_size=9, num_simulation=210, parallel_readouts=4, c_puct1=3, c_puct2=0.05,
                  wu_loss=2, komi=7.5, max_step=120, encode_dim=10, net_blocks=6, net_filters=128, arena_slots=0,
@@ -97,24 +133,16 @@ class SelfPlayEngine:
         return vis, rn, pl, st, ob
 
     def choose_moves(self, visits, steps, selfplay=True):
-        """self_play.py:666-683 per game, in NumPy float64 exactly as the reference writes it.  np.random.choice(A, p)
-        is cdf = p.cumsum(); cdf /= cdf[-1]; cdf.searchsorted(random_sample(), 'right') (NumPy mtrand.pyx) with the
-        uniform drawn from the game's stream."""
+        """self_play.py:666-683 for every live game, in NumPy float64 with the reference's own operations:
+        counts==1 -> 0, pi = counts/sum, p ~ counts**(1/tau), and np.random.choice(A, p) spelt out as NumPy implements it
+        (mtrand.pyx: cdf = p.cumsum(); cdf /= cdf[-1]; cdf.searchsorted(random_sample(), 'right')) with the uniform
+        drawn from the game's own stream.  Vectorised over games; every operation is element-wise or a last-axis
+        reduction, so each row equals the per-game 1-D computation bit for bit (tests/test_host_logic.py checks it
+        against the literal per-game form, choose_moves_reference)."""
         live = ~self.finished
         u = np.zeros(self.G, np.float64)
         self.ctx.call("tg_sp_draw_uniform", _ptr(u), _ptr(live.astype(np.uint8)))
-        actions = np.zeros(self.G, np.int32)
-        pis = np.zeros((self.G, self.A), np.float64)
-        for g in np.flatnonzero(live):
-            counts = np.array([int(c) for c in visits[g]])
-            counts = np.where(counts == 1, 0, counts)
-            pis[g] = counts / np.sum(counts)
-            tau = temperature(int(steps[g])) if selfplay else 0.12
-            powed = np.power(counts, 1.0 / tau)
-            probs = np.array(powed) / np.sum(powed)
-            cdf = probs.cumsum(); cdf /= cdf[-1]
-            actions[g] = cdf.searchsorted(u[g], side="right")
-        return actions, pis
+        return choose_moves_batch(visits, steps, u, live, selfplay)
 
     def play(self, actions):
         """update_with_action (self_play.py:857-872)."""

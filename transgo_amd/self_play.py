@@ -85,6 +85,8 @@ class BatchedSelfPlay:
         self.moves_played = 0
         self.games_finished = 0
         self._started = False
+        self._hist, self._hist_base, self._move_idx = [], 0, 0
+        self._game_start = np.zeros(n_games, np.int64)
 
     def seed_of(self, g):
         """Game seeds s = 1000*rank + g for the first game of a slot, then a fixed stride per restart."""
@@ -110,29 +112,41 @@ class BatchedSelfPlay:
 
     def step(self, selfplay=True):
         """One move of every game: get_action_probs + update_with_action (self_play.py:917-926).  Returns the records
-        of the games that ended with this move; their slots are restarted."""
+        of the games that ended with this move; their slots are restarted.  Per-move material is kept as whole-batch
+        arrays (observations bit-packed) and only sliced per game when a game ends."""
         if not self._started:
             self.start()
         eng = self.engine
         eng.search(selfplay)
         vis, rn, players, steps, obs = eng.root_info(obs=self.keep_obs)
         actions, pis = eng.choose_moves(vis, steps, selfplay)
-        for g in range(self.G):
-            r = self.records[g]
-            if self.keep_obs:
-                r.observations.append(obs[g].copy())
-            r.pis.append(pis[g]); r.visits.append(vis[g].copy()); r.players.append(int(players[g]))
+        packed = np.packbits(obs.reshape(self.G, -1).astype(np.uint8), axis=1) if self.keep_obs else None
+        self._hist.append((packed, vis, players.astype(np.int8)))
         done = eng.play(actions)
         self.moves_played += self.G
         finished = []
         if done.any():
             score, terr, win = eng.final()
+            C, S = self.config.encode_state_channels, self.S
             for g in np.flatnonzero(done):
                 r = self.records[g]
+                first = int(self._game_start[g]) - self._hist_base
+                for pk, vi, pl in self._hist[first:]:
+                    if pk is not None:
+                        r.observations.append(np.unpackbits(pk[g])[:C * S * S].reshape(C, S, S).astype(np.float32))
+                    counts = np.array([int(c) for c in vi[g]])
+                    counts = np.where(counts == 1, 0, counts)                  # self_play.py:666-671
+                    r.visits.append(vi[g].copy()); r.pis.append(counts / np.sum(counts)); r.players.append(int(pl[g]))
                 r.winner, r.territory, r.score = int(win[g]), terr[g].copy(), float(score[g])
                 finished.append(r)
             self.games_finished += len(finished)
             self._reset(done)
+        self._move_idx += 1
+        self._game_start[done] = self._move_idx
+        drop = int(self._game_start.min()) - self._hist_base        # history older than every live game
+        if drop > 0:
+            del self._hist[:drop]
+            self._hist_base += drop
         return finished
 
     def targets(self, record):

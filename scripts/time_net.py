@@ -1,15 +1,14 @@
 """Quick device timing of the network forward at a given batch (development aid)."""
-import ctypes, sys, time
+import ctypes, os, sys, time
 import numpy as np
-sys.path.insert(0, ".")
-from oracle.net import seeded_tower
-from transgo_amd.model import HipNetwork
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from transgo_amd.model import HipNetwork, random_weights
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 NB = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 h = HipNetwork(9, 10, F, NB, rows_cap=B)
-h.set_weights(seeded_tower(9, 10, F, NB).get_weights())
+h.set_weights(random_weights(9, 10, F, NB))
 x = (np.random.RandomState(0).rand(B, 10, 9, 9) < 0.2).astype(np.float32)
 h.main_prediction(x[:256])
 h.ctx.call("tg_prof_enable", 1, 4096)

@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtransgo_hip.so")
+LIB_PATH = os.environ.get("TG_LIB") or os.path.join(_HERE, "libtransgo_hip.so")   # TG_LIB: A/B builds during kernel tuning
 
 
 class TgConfig(ctypes.Structure):

@@ -24,11 +24,12 @@ using namespace tg;
 namespace tg {
 
 struct ConvW { const float* w; const float* b; };
-struct BlockW { const float* s1; const float* t1; ConvW c1; ConvW c2; };
+struct BlockW { const float* s1; const float* t1; ConvW c1; ConvW c2; const float* f1; const float* f2; };   // f1/f2: fragment-ordered copies
 
 struct Net {
     int F = 0, NB = 0, C = 0, S = 0, P = 0, A = 0;
     float* blob = nullptr; size_t blob_floats = 0;
+    float* frag = nullptr;   // [2*NB][F/32][9][2][F/16][64][4] fragment-ordered F->F conv weights
     ConvW stem; std::vector<BlockW> blocks; const float* s_end = nullptr; const float* t_end = nullptr;
     ConvW head; const float* w_vo = nullptr; const float* b_vo = nullptr; const float* w_v = nullptr; const float* b_v = nullptr;
     const float* w_o = nullptr; const float* b_o = nullptr; const float* w_a = nullptr; const float* b_a = nullptr;
@@ -47,7 +48,17 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int TM = 128;         // output rows (positions) per workgroup
+#ifndef TG_WP_CTW
+#define TG_WP_CTW 4          // cout tiles (of 16) per wave in k_conv3x3_wp
+#endif
+#ifndef TG_WP_ACC
+#define TG_WP_ACC 32         // accumulator tiles per wave (x4 registers)
+#endif
+#ifndef TG_WP_CC
+#define TG_WP_CC 16          // input channels per activation slice of k_conv3x3_wp
+#endif
+
+constexpr int TM = 128;         // output rows (positions) per workgroup of k_conv3x3
 
 template <int S>
 __global__ __launch_bounds__(256) void k_obs_to_rows(const float* __restrict__ obs, float* __restrict__ x0, int rows, int C) {
@@ -207,6 +218,160 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, f
     }
 }
 
+
+// ---- EXPERIMENTAL (build with -DTG_CONV_WP; measured 117 TFLOP/s vs 128 for k_conv3x3) ----
+// ---- wave-private 3x3 conv (the F->F convs of the tower: 99 % of the network's FLOPs) ---------------------------------------
+// Every wave is an independent worker: 64 consecutive rows x all COUT channels (4 position tiles x COUT/16 cout tiles of
+// v_mfma_f32_16x16x4_f32, accumulators in registers), NO workgroup barrier anywhere.  Activations: the wave's own 64+2*HALO
+// rows, 32 input channels at a time, in a wave-private LDS slab (+ one all-zero row that out-of-board taps are
+// redirected to, so no masking happens in the MFMA stream).  Weights: never staged -- each A fragment is one fully
+// coalesced 1-KB wave load from a fragment-ordered copy of the weights ([slice][tap][sub][cout tile][lane][4], built at load
+// time) that streams linearly through L2/L1, four fragments (= 64 MFMAs) ahead of use.
+template <int S, int F, bool PRO, int EPI, int NPT, int CTW>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_wp(const float* __restrict__ in, float* __restrict__ out,
+                                                       const float* __restrict__ res, const float* __restrict__ Wf,
+                                                       const float* __restrict__ bias, const float* __restrict__ ps,
+                                                       const float* __restrict__ pt, int M) {
+    constexpr int P = S * S, HALO = S + 1, WT = 16 * NPT;
+    constexpr int CC = TG_WP_CC, RS = CC + 4, C4 = CC / 4, NSUB = CC / 16;
+    constexpr int NROW = WT + 2 * HALO;              // rows staged per wave
+    constexpr int ZROW = NROW;                       // index of the all-zero row
+    constexpr int CT = CTW;                          // cout tiles held by this wave
+    constexpr int NG = (F / 16) / CTW;               // cout groups: NG waves share one row block
+    constexpr int XL = (NROW * C4 + 63) / 64;        // activation float4 per lane per slice
+    constexpr int NFRAG = (F / CC) * 9 * NSUB * CT;  // A fragments per tile
+    constexpr int DEPTH = ((CC / 16) * CTW) % 4 == 0 ? 4 : 2;   // fragments in flight
+    static_assert((NSUB * CT) % DEPTH == 0, "prefetch ring must divide the fragments of one tap");
+    __shared__ float lds[4][(NROW + 1) * RS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j = lane & 15, kq = lane >> 4;
+    const int wid = blockIdx.x * 4 + wave;
+    const int cg = wid % NG;                         // which CTW*16 couts
+    const int m0 = (wid / NG) * WT;
+    if (m0 >= M) return;                             // whole wave out of range (no barriers in this kernel)
+    float* xs = lds[wave];
+
+    int vrow[NPT];                                   // LDS row of each position tile's lane row, before the tap offset
+    unsigned vmask[NPT];
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) {
+        const int m = m0 + t * 16 + j;
+        unsigned mk = 0;
+        if (m < M) {
+            const int p = m % P, x = p % S, y = p / S;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                if (yy >= 0 && yy < S && xx >= 0 && xx < S) mk |= 1u << tap;
+            }
+        }
+        vmask[t] = mk;
+        vrow[t] = t * 16 + j + HALO;
+    }
+    for (int i = lane; i < RS; i += 64) xs[ZROW * RS + i] = 0.f;
+
+    f32x4 acc[CT][NPT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int t = 0; t < NPT; ++t) acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 xreg[XL];
+    auto load_x = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+            const int idx = lane + i * 64;
+            xreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (idx < NROW * C4) {
+                const int r = idx / C4, c4 = idx % C4;
+                const int m = m0 - HALO + r;
+                if (m >= 0 && m < M) xreg[i] = *reinterpret_cast<const f32x4*>(in + (size_t)m * F + cc + c4 * 4);
+            }
+        }
+    };
+    auto store_x = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+            const int idx = lane + i * 64;
+            if (idx < NROW * C4) {
+                const int r = idx / C4, c4 = idx % C4;
+                f32x4 v = xreg[i];
+                if (PRO) {
+                    const int m = m0 - HALO + r;
+                    if (m >= 0 && m < M) {
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(ps + cc + c4 * 4);
+                        const f32x4 sh = *reinterpret_cast<const f32x4*>(pt + cc + c4 * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { float u = v[e] * sc[e] + sh[e]; v[e] = u > 0.f ? u : 0.f; }
+                    }
+                }
+                *reinterpret_cast<f32x4*>(&xs[r * RS + c4 * 4]) = v;
+            }
+        }
+    };
+
+    const f32x4* wf = reinterpret_cast<const f32x4*>(Wf) + (size_t)cg * NFRAG * 64 + lane;   // fragment f of this cout group at wf[f * 64]
+    f32x4 aq[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) aq[d] = wf[(size_t)d * 64];
+    int fbase = 0;                                                   // index of the fragment held in aq[0]
+
+    load_x(0);
+    store_x(0);
+    // wave-private LDS needs no fence: one wave's DS instructions execute in issue order, and the compiler keeps the
+    // order of possibly-aliasing accesses to the same array
+
+    for (int cc = 0; cc < F; cc += CC) {
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap == 8 && cc + CC < F) load_x(cc + CC);            // next slice lands while this tap computes
+            const int toff = (tap / 3 - 1) * S + (tap % 3 - 1);
+            int brow[NPT];
+#pragma unroll
+            for (int t = 0; t < NPT; ++t) brow[t] = ((vmask[t] >> tap) & 1) ? (vrow[t] + toff) : ZROW;
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) {
+                f32x4 b[NPT];
+#pragma unroll
+                for (int t = 0; t < NPT; ++t) b[t] = *reinterpret_cast<const f32x4*>(&xs[brow[t] * RS + sub * 16 + kq * 4]);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int q = (sub * CT + ct) % DEPTH;
+                    const f32x4 a = aq[q];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                        for (int t = 0; t < NPT; ++t)
+                            acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[t][s4], acc[ct][t], 0, 0, 0);
+                    int fn = fbase + sub * CT + ct + DEPTH;
+                    fn = fn < NFRAG ? fn : NFRAG - 1;                // past the end: harmless re-read
+                    aq[q] = wf[(size_t)fn * 64];
+                    __builtin_amdgcn_sched_barrier(0);               // keep the load HERE: hipcc otherwise sinks it to its use
+                }
+            }
+            fbase += NSUB * CT;
+        }
+        if (cc + CC < F) store_x(cc + CC);
+    }
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) {
+        const int m = m0 + t * 16 + j;
+        if (m >= M) continue;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int co = (cg * CTW + ct) * 16 + kq * 4;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + co);
+            f32x4 v = acc[ct][t] + bv;
+            if (EPI == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            } else {
+                v = v + *reinterpret_cast<const f32x4*>(res + (size_t)m * F + co);
+            }
+            *reinterpret_cast<f32x4*>(out + (size_t)m * F + co) = v;
+        }
+    }
+}
+
 // Heads after the shared 3x3 conv (hc[row][p][16]: channels 0-1 value/own, 2-5 policy; BN+ReLU already applied).
 template <int S>
 __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ hc, const float* __restrict__ w_vo,
@@ -273,6 +438,13 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
     hipStream_t st = ctx->stream;
     const int M = rows * P;
     const int grid = (M + TM - 1) / TM;
+    // k_conv3x3_wp: independent waves of (16*WP_NPT rows) x (16*WP_CTW couts); 4 waves per workgroup
+    constexpr int WP_CTW = (F / 16) < TG_WP_CTW ? (F / 16) : TG_WP_CTW;
+    constexpr int WP_NPT = TG_WP_ACC / WP_CTW;
+    constexpr int WP_NG = (F / 16) / WP_CTW;
+    const int n_waves = ((M + 16 * WP_NPT - 1) / (16 * WP_NPT)) * WP_NG;
+    const int grid_w = (n_waves + 3) / 4;
+    (void)grid_w;
     const double conv_flops = 2.0 * 9.0 * (double)F * (double)F * (double)M;
     int g0 = (int)(((size_t)M * 16 + 255) / 256); if (g0 > 65535) g0 = 65535;
     hipLaunchKernelGGL((k_obs_to_rows<S>), dim3(g0), dim3(256), 0, st, obs, n->x0, rows, n->C);
@@ -281,11 +453,23 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
     float* x = n->bufA; float* y = n->bufB;
     for (const BlockW& b : n->blocks) {
         { ProfScope ps(n, st, conv_flops);
+#ifdef TG_CONV_WP
+          hipLaunchKernelGGL((k_conv3x3_wp<S, F, true, 0, WP_NPT, WP_CTW>), dim3(grid_w), dim3(256), 0, st, (const float*)x, n->bufH,
+                             (const float*)nullptr, b.f1, b.c1.b, b.s1, b.t1, M);
+#else
           hipLaunchKernelGGL((k_conv3x3<S, F, F, true, 0>), dim3(grid), dim3(256), 0, st, (const float*)x, n->bufH,
-                             (const float*)nullptr, b.c1.w, b.c1.b, b.s1, b.t1, M); }
+                             (const float*)nullptr, b.c1.w, b.c1.b, b.s1, b.t1, M);
+#endif
+        }
         { ProfScope ps(n, st, conv_flops);
+#ifdef TG_CONV_WP
+          hipLaunchKernelGGL((k_conv3x3_wp<S, F, false, 1, WP_NPT, WP_CTW>), dim3(grid_w), dim3(256), 0, st, (const float*)n->bufH, y,
+                             (const float*)x, b.f2, b.c2.b, (const float*)nullptr, (const float*)nullptr, M);
+#else
           hipLaunchKernelGGL((k_conv3x3<S, F, F, false, 1>), dim3(grid), dim3(256), 0, st, (const float*)n->bufH, y,
-                             (const float*)x, b.c2.w, b.c2.b, (const float*)nullptr, (const float*)nullptr, M); }
+                             (const float*)x, b.c2.w, b.c2.b, (const float*)nullptr, (const float*)nullptr, M);
+#endif
+        }
         float* t = x; x = y; y = t;
     }
     hipLaunchKernelGGL((k_conv3x3<S, F, 16, true, 0>), dim3(grid), dim3(256), 0, st, (const float*)x, n->hc,
@@ -352,6 +536,7 @@ int tg_net_load(tg_ctx* ctx, const float* blob, size_t n_floats, int rows_cap) {
         TG_HIP(ctx, hipMalloc((void**)&n->x0, sizeof(float) * (size_t)rows_cap * P * 16));
         TG_HIP(ctx, hipMalloc((void**)&n->hc, sizeof(float) * (size_t)rows_cap * P * 16));
         TG_HIP(ctx, hipMalloc((void**)&n->own, sizeof(float) * (size_t)rows_cap * P));
+        TG_HIP(ctx, hipMalloc((void**)&n->frag, sizeof(float) * (size_t)(NB > 0 ? 2 * NB : 1) * 9 * F * F));
         const float* p = n->blob;
         auto take = [&](size_t k) { const float* q = p; p += k; return q; };
         n->stem.w = take(9 * (size_t)F * 16); n->stem.b = take(F);
@@ -368,14 +553,45 @@ int tg_net_load(tg_ctx* ctx, const float* blob, size_t n_floats, int rows_cap) {
     }
     // weight refresh (trainer.py:76-79 -> self_play.py:913) is just this copy
     TG_HIP(ctx, hipMemcpyAsync(n->blob, blob, sizeof(float) * n_floats, hipMemcpyHostToDevice, ctx->stream));
-    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // fragment-ordered copies of the F->F conv weights for k_conv3x3_wp:
+    //   frag f = group*NFRAG + ((slice*9 + tap)*NSUB + sub)*CTW + ct ; element [f][lane][e] = W[tap][ct*16 + (lane&15)][slice*CC + sub*16 + (lane>>4)*4 + e]
+    {
+        const size_t per = 9 * (size_t)F * F;
+        const int CT = F / 16;
+        std::vector<float> fr(per * (n->blocks.empty() ? 1 : 2 * n->blocks.size()));
+        auto repack = [&](const float* w, float* dst) {
+            constexpr int WCC = TG_WP_CC, NSUB = WCC / 16;
+            const int CTW = CT < TG_WP_CTW ? CT : TG_WP_CTW, NG = CT / CTW;
+            const size_t nfrag = (size_t)(F / WCC) * 9 * NSUB * CTW;
+            for (int cg = 0; cg < NG; ++cg)
+                for (int sl = 0; sl < F / WCC; ++sl)
+                    for (int tap = 0; tap < 9; ++tap)
+                        for (int sub = 0; sub < NSUB; ++sub)
+                            for (int ct = 0; ct < CTW; ++ct) {
+                                const size_t f = cg * nfrag + ((size_t)(sl * 9 + tap) * NSUB + sub) * CTW + ct;
+                                for (int lane = 0; lane < 64; ++lane)
+                                    for (int e = 0; e < 4; ++e)
+                                        dst[(f * 64 + lane) * 4 + e] =
+                                            w[((size_t)tap * F + (cg * CTW + ct) * 16 + (lane & 15)) * F + sl * WCC + sub * 16 + (lane >> 4) * 4 + e];
+                            }
+        };
+        for (size_t i = 0; i < n->blocks.size(); ++i) {
+            BlockW& b = n->blocks[i];
+            repack(blob + (b.c1.w - n->blob), fr.data() + (2 * i) * per);
+            repack(blob + (b.c2.w - n->blob), fr.data() + (2 * i + 1) * per);
+            b.f1 = n->frag + (2 * i) * per; b.f2 = n->frag + (2 * i + 1) * per;
+        }
+        if (!n->blocks.empty())
+            TG_HIP(ctx, hipMemcpyAsync(n->frag, fr.data(), sizeof(float) * fr.size(), hipMemcpyHostToDevice, ctx->stream));
+        TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return TG_OK;
 }
 
 void tg_net_destroy(tg_ctx* ctx) {
     if (!ctx || !ctx->eng || !ctx->eng->net) return;
     Net* n = ctx->eng->net;
-    void* ptrs[] = {n->blob, n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own};
+    void* ptrs[] = {n->blob, n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->frag};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t ev : n->ev) (void)hipEventDestroy(ev);
     delete n;

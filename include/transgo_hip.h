@@ -155,6 +155,11 @@ int tg_sp_stats(tg_ctx* ctx, uint64_t* sims, uint64_t* evals, uint64_t* depth_su
  * self_play.py:913.  rows_cap: largest batch tg_net_predict will be asked for (engine contexts size it themselves). */
 size_t tg_net_blob_floats(int board_size, int encode_dim, int filters, int blocks);
 int tg_net_load(tg_ctx* ctx, const float* blob, size_t n_floats, int rows_cap);
+/* Same with an explicit layer program: one letter per trunk layer, 'R' = pre-activation ResidualBlock (model.py:238-248),
+ * 'A' = Self_Attention (model.py:288-315), optional "+P" = attention in the policy head (model.py:72,106).  The shipped
+ * MainNetwork (model.py:49-76) is "RARRRARRRRAR+P"; tg_net_load uses cfg.net_blocks x 'R'.  Attention needs 9x9. */
+size_t tg_net_blob_floats_arch(int board_size, int encode_dim, int filters, const char* arch);
+int tg_net_load_arch(tg_ctx* ctx, const char* arch, const float* blob, size_t n_floats, int rows_cap);
 /* main_prediction (model.py:17-20) on host buffers: obs f32[n][C][S][S] -> policy f32[n][A] (softmax), value f32[n]
  * (tanh), own f32[n][S*S] (tanh; may be NULL). */
 int tg_net_predict(tg_ctx* ctx, const float* obs, int n_rows, float* policy, float* value, float* own);

@@ -36,6 +36,68 @@ class PreActBlock(nn.Module):                # ResidualBlock with input_dim == o
         return x + y
 
 
+class SelfAttention(nn.Module):              # Self_Attention, model.py:288-315
+    def __init__(self, f):
+        super().__init__()
+        self.query_conv = nn.Conv2d(f, f // 4, 1)
+        self.key_conv = nn.Conv2d(f, f // 4, 1)
+        self.value_conv = nn.Conv2d(f, f, 1)
+        self.gamma = nn.Parameter(torch.zeros(1))
+        self.bn = nn.BatchNorm2d(f)
+
+    def forward(self, x):
+        b, c, w, h = x.size()
+        q = self.query_conv(x).view(b, -1, w * h).permute(0, 2, 1)
+        k = self.key_conv(x).view(b, -1, w * h)
+        att = torch.softmax(torch.bmm(q, k), dim=-1)
+        v = self.value_conv(x).view(b, -1, w * h)
+        out = torch.bmm(v, att).view(b, c, w, h)          # sums over the softmaxed row index, as the reference does
+        return F.relu(self.bn(self.gamma * out + x))
+
+
+class TransGoMainBody(nn.Module):
+    """MainNetwork (model.py:41-114) with its module names, so the reference state_dict loads unchanged."""
+
+    def __init__(self, board_size, input_dim, f):
+        super().__init__()
+        self.S = board_size
+        P = board_size * board_size
+        self.conv1 = ConvBnRelu(input_dim, f)
+        for i in range(2, 14):
+            setattr(self, f"res_conv{i}", SelfAttention(f) if i in (3, 7, 12) else PreActBlock(f))
+        self.bn_res_end = nn.BatchNorm2d(f)
+        self.conv_val_own = ConvBnRelu(f, 2)
+        self.fc_val_own = nn.Linear(2 * P, 64)
+        self.fc_val = nn.Linear(64, 1)
+        self.fc_own = nn.Linear(64, P)
+        self.attention_act = SelfAttention(f)
+        self.conv_act = ConvBnRelu(f, 4)
+        self.fc_act = nn.Linear(4 * P, P + 1)
+
+    def forward(self, x):
+        P = self.S * self.S
+        x = self.conv1(x)
+        for i in range(2, 14):
+            x = getattr(self, f"res_conv{i}")(x)
+        x = F.relu(self.bn_res_end(x))
+        h = F.relu(self.fc_val_own(self.conv_val_own(x).view(-1, 2 * P)))
+        val = torch.tanh(self.fc_val(h))
+        own = torch.tanh(self.fc_own(h))
+        act = torch.softmax(self.fc_act(self.conv_act(self.attention_act(x)).view(-1, 4 * P)), -1)
+        return act, val, own
+
+
+class TransGoMain(nn.Module):
+    """TransGoNetwork surface (model.py:11-27) around TransGoMainBody."""
+
+    def __init__(self, board_size=9, input_dim=10, filters=128):
+        super().__init__()
+        self.main_network = TransGoMainBody(board_size, input_dim, filters)
+
+    def main_prediction(self, state):
+        return self.main_network(state)
+
+
 class TowerBody(nn.Module):
     def __init__(self, board_size, input_dim, filters, blocks):
         super().__init__()

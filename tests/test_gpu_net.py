@@ -63,3 +63,45 @@ def test_engine_with_network_smoke():
         eng.play(acts)
     s = eng.stats()
     assert s["errors"] == 0 and s["sims"] >= 3 * G * sims
+
+
+def test_reference_mainnetwork_with_attention(golden_dir):
+    """The shipped MainNetwork layout (9 residual + 3 attention blocks, attention policy head, model.py:49-76) with the
+    reference's own state_dict, against outputs recorded from the imported reference model."""
+    import os
+    from transgo_amd.model import HipNetwork, transgo_arch
+    with np.load(os.path.join(golden_dir, "net_transgo_f32.npz")) as z:
+        b = {k: z[k] for k in z.files}
+    sd = {k[3:]: v for k, v in b.items() if k.startswith("sd/")}
+    h = HipNetwork(9, 10, 32, rows_cap=8, arch=transgo_arch())
+    h.set_weights(sd)
+    hp, hv, ho = h.main_prediction(b["x"])
+    ep, ev, eo = np.abs(hp - b["policy"]).max(), np.abs(hv - b["value"]).max(), np.abs(ho - b["own"]).max()
+    print(f"MainNetwork F=32: max abs err policy {ep:.2e} value {ev:.2e} own {eo:.2e}")
+    assert ep < TOL and ev < TOL and eo < TOL
+
+
+def test_mainnetwork_default_width_vs_oracle():
+    """F=128 (the reference default, configure.py:37) against the torch restatement that the fixture above pins."""
+    import torch
+    from oracle.net import TransGoMain
+    from transgo_amd.model import HipNetwork, transgo_arch
+    torch.manual_seed(3); torch.set_num_threads(4)
+    net = TransGoMain(9, 10, 128).eval()
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+            if hasattr(m, "gamma"):
+                m.gamma.copy_(0.5 + torch.rand(1, generator=g))
+    x = _positions(9, 70, 11)
+    with torch.no_grad():
+        p, v, o = net.main_prediction(torch.from_numpy(x))
+    h = HipNetwork(9, 10, 128, rows_cap=64, arch=transgo_arch())
+    h.set_weights({k: t.numpy() for k, t in net.state_dict().items()})
+    hp, hv, ho = h.main_prediction(x)
+    ep, ev, eo = np.abs(hp - p.numpy()).max(), np.abs(hv - v.numpy()).max(), np.abs(ho - o.numpy()).max()
+    print(f"MainNetwork F=128: max abs err policy {ep:.2e} value {ev:.2e} own {eo:.2e}")
+    assert ep < TOL and ev < TOL and eo < TOL

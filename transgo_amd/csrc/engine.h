@@ -51,3 +51,4 @@ struct Engine {
 
 extern "C" int tg_net_forward(tg_ctx* ctx, int rows);   // obs[rows] -> policy[rows], value[rows] on ctx->stream
 extern "C" void tg_net_destroy(tg_ctx* ctx);
+extern "C" int tg_net_load_arch(tg_ctx* ctx, const char* arch, const float* blob, size_t n_floats, int rows_cap);

@@ -15,6 +15,7 @@
 // of materialising padded boards.  BatchNorm is folded on the host (transgo_amd/model.py): BN that follows a conv goes
 // into its weights/bias, BN that precedes one (pre-activation) is applied with ReLU while the tile is staged into LDS.
 #include <cmath>
+#include <string>
 #include <vector>
 
 #include "engine.h"
@@ -25,12 +26,16 @@ namespace tg {
 
 struct ConvW { const float* w; const float* b; };
 struct BlockW { const float* s1; const float* t1; ConvW c1; ConvW c2; const float* f1; const float* f2; };   // f1/f2: fragment-ordered copies
+struct AttW { ConvW qkv; const float* gamma; const float* s; const float* t; };      // Self_Attention, model.py:288-315
+struct Layer { int kind; int ridx; AttW a; };                                         // kind 0: residual block blocks[ridx]; 1: attention
 
 struct Net {
     int F = 0, NB = 0, C = 0, S = 0, P = 0, A = 0;
     float* blob = nullptr; size_t blob_floats = 0;
     float* frag = nullptr;   // [2*NB][F/32][9][2][F/16][64][4] fragment-ordered F->F conv weights
-    ConvW stem; std::vector<BlockW> blocks; const float* s_end = nullptr; const float* t_end = nullptr;
+    ConvW stem; std::vector<BlockW> blocks; std::vector<Layer> layers; const float* s_end = nullptr; const float* t_end = nullptr;
+    bool pol_att = false; AttW patt; ConvW head_a; std::string arch;
+    float* bufQ = nullptr; float* hca = nullptr;   // q|k|v projections [rows][P][1.5F]; policy head conv output
     ConvW head; const float* w_vo = nullptr; const float* b_vo = nullptr; const float* w_v = nullptr; const float* b_v = nullptr;
     const float* w_o = nullptr; const float* b_o = nullptr; const float* w_a = nullptr; const float* b_a = nullptr;
     float* x0 = nullptr;   // [rows][P][16] input planes, channel-minor
@@ -73,13 +78,14 @@ __global__ __launch_bounds__(256) void k_obs_to_rows(const float* __restrict__ o
     }
 }
 
-// EPI 0: out = relu(acc + bias)      EPI 1: out = acc + bias + res
-template <int S, int CIN, int COUT, bool PRO, int EPI>
+// EPI 0: out = relu(acc + bias)      EPI 1: out = acc + bias + res      EPI 2: out = acc + bias
+// NTAP 9: 3x3 convolution with zero padding; NTAP 1: 1x1 convolution (the q/k/v projections of Self_Attention, model.py:294-296)
+template <int S, int CIN, int COUT, bool PRO, int EPI, int NTAP = 9>
 __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, float* __restrict__ out,
                                                  const float* __restrict__ res, const float* __restrict__ Wt,
                                                  const float* __restrict__ bias, const float* __restrict__ ps,
                                                  const float* __restrict__ pt, int M) {
-    constexpr int P = S * S, HALO = S + 1;
+    constexpr int P = S * S, HALO = NTAP == 9 ? S + 1 : 0;
     constexpr int CC = CIN < 32 ? CIN : 32;         // input channels staged per pass
     constexpr int RS = CC + 4;                      // LDS row stride (floats)
     constexpr int NROW = TM + 2 * HALO;
@@ -103,6 +109,7 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, f
                 const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
                 if (yy >= 0 && yy < S && xx >= 0 && xx < S) mk |= 1u << tap;
             }
+            if (NTAP == 1) mk = 1u;
         }
         vmask[t] = mk;
     }
@@ -168,14 +175,14 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, f
     load_x(0);
     load_w(0, 0);
     for (int cc = 0; cc < CIN; cc += CC) {
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < NTAP; ++tap) {
             __syncthreads();
             if (tap == 0) store_x(cc);
             store_w();
             __syncthreads();
-            if (tap < 8) load_w(cc, tap + 1);
+            if (tap < NTAP - 1) load_w(cc, tap + 1);
             else if (cc + CC < CIN) { load_w(cc + CC, 0); load_x(cc + CC); }
-            const int toff = (tap / 3 - 1) * S + (tap % 3 - 1);
+            const int toff = NTAP == 9 ? (tap / 3 - 1) * S + (tap % 3 - 1) : 0;
 #pragma unroll
             for (int sub = 0; sub < CC / 16; ++sub) {
                 f32x4 b[2];
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, f
             if (EPI == 0) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-            } else {
+            } else if (EPI == 1) {
                 v = v + *reinterpret_cast<const f32x4*>(res + (size_t)m * COUT + co);
             }
             *reinterpret_cast<f32x4*>(out + (size_t)m * COUT + co) = v;
@@ -372,9 +379,57 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wp(const float* __restrict__
     }
 }
 
-// Heads after the shared 3x3 conv (hc[row][p][16]: channels 0-1 value/own, 2-5 policy; BN+ReLU already applied).
+
+// Self_Attention core (model.py:301-315) for one board per workgroup, after the fused q/k/v 1x1 projection:
+//   energy[i][j] = q_i . k_j ; attention = softmax_j(energy) ; out[:, j] = sum_i v[:, i] * attention[i][j]   (note: summed over
+//   the softmaxed ROW index i, exactly as torch.bmm(proj_value, attention) does)
+//   y = relu(bn(gamma * out + x))            -- x optionally pre-activated with relu(x*ps+pt) (policy head, model.py:94,106)
+template <int S, int F>
+__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, const float* __restrict__ xin,
+                                                   float* __restrict__ out, const float* __restrict__ gamma,
+                                                   const float* __restrict__ bs, const float* __restrict__ bt,
+                                                   const float* __restrict__ ps, const float* __restrict__ pt) {
+    constexpr int P = S * S, FQ = F / 4, W = 2 * FQ + F;
+    extern __shared__ float sm[];
+    float* q = sm;                    // [P][W] rows: q | k | v
+    float* at = sm + P * W;           // [P][P+1]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* src = qkv + (size_t)b * P * W;
+    for (int i = tid; i < P * W / 4; i += 256) reinterpret_cast<f32x4*>(q)[i] = reinterpret_cast<const f32x4*>(src)[i];
+    __syncthreads();
+    for (int e = tid; e < P * P; e += 256) {
+        const int i = e / P, j = e % P;
+        const float* qi = q + i * W; const float* kj = q + j * W + FQ;
+        float a = 0.f;
+        for (int c = 0; c < FQ; ++c) a = fmaf(qi[c], kj[c], a);
+        at[i * (P + 1) + j] = a;
+    }
+    __syncthreads();
+    for (int i = tid; i < P; i += 256) {
+        float* r = at + i * (P + 1);
+        float mx = r[0];
+        for (int j = 1; j < P; ++j) mx = r[j] > mx ? r[j] : mx;
+        float sum = 0.f;
+        for (int j = 0; j < P; ++j) { float e = expf(r[j] - mx); r[j] = e; sum += e; }
+        const float inv = 1.f / sum;
+        for (int j = 0; j < P; ++j) r[j] *= inv;
+    }
+    __syncthreads();
+    const float g = gamma[0];
+    for (int e = tid; e < P * F; e += 256) {
+        const int j = e / F, c = e % F;
+        float a = 0.f;
+        for (int i = 0; i < P; ++i) a = fmaf(q[i * W + 2 * FQ + c], at[i * (P + 1) + j], a);
+        float x = xin[((size_t)b * P + j) * F + c];
+        if (ps) { x = x * ps[c] + pt[c]; x = x > 0.f ? x : 0.f; }
+        float y = (g * a + x) * bs[c] + bt[c];
+        out[((size_t)b * P + j) * F + c] = y > 0.f ? y : 0.f;
+    }
+}
+
+// Heads after the 3x3 head convs (hc[row][p][16]: channels 0-1 value/own, 2-5 policy; BN+ReLU already applied).
 template <int S>
-__global__ __launch_bounds__(256) void k_heads(const float* __restrict__ hc, const float* __restrict__ w_vo,
+__global__ __launch_bounds__(256) void k_heads(const float* __restrict__ hc, const float* __restrict__ hca, const float* __restrict__ w_vo,
                                                const float* __restrict__ b_vo, const float* __restrict__ w_v,
                                                const float* __restrict__ b_v, const float* __restrict__ w_o,
                                                const float* __restrict__ b_o, const float* __restrict__ w_a,
@@ -386,7 +441,10 @@ __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ hc, con
     __shared__ float logit[A];
     __shared__ float red[2];
     const int row = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < 6 * P; i += 256) { const int c = i / P, p = i % P; hin[i] = hc[((size_t)row * P + p) * 16 + c]; }
+    for (int i = tid; i < 6 * P; i += 256) {           // channels 0-1 from the value conv, 2-5 from the policy conv
+        const int c = i / P, p = i % P;
+        hin[i] = (c < 2 ? hc : hca)[((size_t)row * P + p) * 16 + c];
+    }
     __syncthreads();
     if (tid < 64) {                                                   // fc_val_own + ReLU (model.py:99)
         float a = b_vo[tid];
@@ -451,7 +509,28 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
     hipLaunchKernelGGL((k_conv3x3<S, 16, F, false, 0>), dim3(grid), dim3(256), 0, st, (const float*)n->x0, n->bufA,
                        (const float*)nullptr, n->stem.w, n->stem.b, (const float*)nullptr, (const float*)nullptr, M);
     float* x = n->bufA; float* y = n->bufB;
-    for (const BlockW& b : n->blocks) {
+    // attention block: fused q|k|v 1x1 projection on the matrix cores, then the per-board core (model.py:301-315)
+    constexpr int W = F / 4 + F / 4 + F;
+    constexpr size_t att_lds = sizeof(float) * ((size_t)P * W + (size_t)P * (P + 1));
+    auto attention = [&](const AttW& a, const float* xin, float* xout, const float* ps, const float* pt) -> int {
+        if (att_lds > 160 * 1024) return -1;
+        if (ps)
+            hipLaunchKernelGGL((k_conv3x3<S, F, W, true, 2, 1>), dim3(grid), dim3(256), 0, st, xin, n->bufQ,
+                               (const float*)nullptr, a.qkv.w, a.qkv.b, ps, pt, M);
+        else
+            hipLaunchKernelGGL((k_conv3x3<S, F, W, false, 2, 1>), dim3(grid), dim3(256), 0, st, xin, n->bufQ,
+                               (const float*)nullptr, a.qkv.w, a.qkv.b, (const float*)nullptr, (const float*)nullptr, M);
+        hipLaunchKernelGGL((k_attention<S, F>), dim3(rows), dim3(256), att_lds, st, (const float*)n->bufQ, xin, xout,
+                           a.gamma, a.s, a.t, ps, pt);
+        return 0;
+    };
+    for (const Layer& L : n->layers) {
+        if (L.kind == 1) {
+            if (attention(L.a, x, y, nullptr, nullptr)) TG_FAIL(ctx, TG_ERR_ARG, "attention blocks need P*(1.5F+P+1) floats of LDS: not available at this board size");
+            float* t = x; x = y; y = t;
+            continue;
+        }
+        const BlockW& b = n->blocks[L.ridx];
         { ProfScope ps(n, st, conv_flops);
 #ifdef TG_CONV_WP
           hipLaunchKernelGGL((k_conv3x3_wp<S, F, true, 0, WP_NPT, WP_CTW>), dim3(grid_w), dim3(256), 0, st, (const float*)x, n->bufH,
@@ -472,9 +551,18 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
         }
         float* t = x; x = y; y = t;
     }
+    // heads: value/ownership conv reads relu(bn_end(x)) (model.py:94,97); the policy conv reads the same tensor, or its
+    // Self_Attention when the architecture has attention_act (model.py:72,106-107)
     hipLaunchKernelGGL((k_conv3x3<S, F, 16, true, 0>), dim3(grid), dim3(256), 0, st, (const float*)x, n->hc,
                        (const float*)nullptr, n->head.w, n->head.b, n->s_end, n->t_end, M);
-    hipLaunchKernelGGL((k_heads<S>), dim3(rows), dim3(256), 0, st, (const float*)n->hc, n->w_vo, n->b_vo, n->w_v, n->b_v,
+    const float* hca = n->hc;
+    if (n->pol_att) {
+        if (attention(n->patt, x, y, n->s_end, n->t_end)) TG_FAIL(ctx, TG_ERR_ARG, "attention policy head: not enough LDS at this board size");
+        hipLaunchKernelGGL((k_conv3x3<S, F, 16, false, 0>), dim3(grid), dim3(256), 0, st, (const float*)y, n->hca,
+                           (const float*)nullptr, n->head_a.w, n->head_a.b, (const float*)nullptr, (const float*)nullptr, M);
+        hca = n->hca;
+    }
+    hipLaunchKernelGGL((k_heads<S>), dim3(rows), dim3(256), 0, st, (const float*)n->hc, hca, n->w_vo, n->b_vo, n->w_v, n->b_v,
                        n->w_o, n->b_o, n->w_a, n->b_a, policy, value, own);
     TG_HIP(ctx, hipGetLastError());
     return TG_OK;
@@ -490,12 +578,29 @@ int forward(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, floa
     TG_FAIL(ctx, TG_ERR_ARG, "unsupported (board_size, net_filters): built are 9x{32,64,128,256}, 19x{128,256}");
 }
 
-size_t expected_floats(int S, int C, int F, int NB) {
-    const size_t P = (size_t)S * S, A = P + 1;
+// arch: one letter per trunk layer, 'R' residual block / 'A' Self_Attention block, optional "+P" = attention in the policy
+// head.  The reference MainNetwork (model.py:49-76) is "RARRRARRRRAR+P"; BASELINE's N-block tower is N x 'R'.
+bool parse_arch(const std::string& arch, std::string* trunk, bool* pol) {
+    *pol = false; *trunk = arch;
+    const size_t plus = arch.find('+');
+    if (plus != std::string::npos) {
+        if (arch.substr(plus) != "+P") return false;
+        *pol = true; *trunk = arch.substr(0, plus);
+    }
+    for (char c : *trunk) if (c != 'R' && c != 'A') return false;
+    return true;
+}
+
+size_t expected_floats(int S, int C, int F, const std::string& arch) {
+    const size_t P = (size_t)S * S, A = P + 1, Wq = (size_t)F / 4 * 2 + F;
     (void)C;
+    std::string trunk; bool pol;
+    if (!parse_arch(arch, &trunk, &pol)) return 0;
+    const size_t att = Wq * F + Wq + 1 + 2 * (size_t)F;
     size_t n = 9 * (size_t)F * 16 + F;
-    n += (size_t)NB * (2 * (size_t)F + 2 * (9 * (size_t)F * F + F));
+    for (char c : trunk) n += (c == 'R') ? (2 * (size_t)F + 2 * (9 * (size_t)F * F + F)) : att;
     n += 2 * (size_t)F;
+    if (pol) n += att + 9 * 16 * (size_t)F + 16;
     n += 9 * 16 * (size_t)F + 16;
     n += 2 * P * 64 + 64 + 64 + 1 + 64 * P + P + 4 * P * A + A;
     return n;
@@ -506,27 +611,42 @@ size_t expected_floats(int S, int C, int F, int NB) {
 extern "C" {
 
 size_t tg_net_blob_floats(int board_size, int encode_dim, int filters, int blocks) {
-    return expected_floats(board_size, encode_dim, filters, blocks);
+    return expected_floats(board_size, encode_dim, filters, std::string((size_t)(blocks > 0 ? blocks : 0), 'R'));
+}
+
+size_t tg_net_blob_floats_arch(int board_size, int encode_dim, int filters, const char* arch) {
+    return arch ? expected_floats(board_size, encode_dim, filters, arch) : 0;
 }
 
 int tg_net_load(tg_ctx* ctx, const float* blob, size_t n_floats, int rows_cap) {
-    if (!ctx || !blob) return TG_ERR_ARG;
+    if (!ctx) return TG_ERR_ARG;
+    const std::string arch((size_t)(ctx->cfg.net_blocks > 0 ? ctx->cfg.net_blocks : 0), 'R');
+    return tg_net_load_arch(ctx, arch.c_str(), blob, n_floats, rows_cap);
+}
+
+int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t n_floats, int rows_cap) {
+    if (!ctx || !blob || !arch_c) return TG_ERR_ARG;
     TG_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    const int S = ctx->S, C = ctx->cfg.encode_dim, F = ctx->cfg.net_filters, NB = ctx->cfg.net_blocks;
+    const int S = ctx->S, C = ctx->cfg.encode_dim, F = ctx->cfg.net_filters;
+    const std::string arch(arch_c);
+    std::string trunk; bool pol = false;
+    if (!parse_arch(arch, &trunk, &pol)) TG_FAIL(ctx, TG_ERR_ARG, "bad architecture string (letters R/A, optional +P)");
     if (C > 16) TG_FAIL(ctx, TG_ERR_ARG, "encode_dim > 16 not supported by the stem kernel");
-    if (F % 32 != 0 || NB < 0) TG_FAIL(ctx, TG_ERR_ARG, "net_filters must be a multiple of 32");
-    if (n_floats != expected_floats(S, C, F, NB)) TG_FAIL(ctx, TG_ERR_ARG, "weight blob size does not match (board_size, filters, blocks)");
+    if (F % 32 != 0) TG_FAIL(ctx, TG_ERR_ARG, "net_filters must be a multiple of 32");
+    if (n_floats != expected_floats(S, C, F, arch)) TG_FAIL(ctx, TG_ERR_ARG, "weight blob size does not match (board_size, filters, architecture)");
     if (!ctx->eng) { ctx->eng = new Engine(); }          // rules-only context + network: a bare evaluator
     Engine* e = ctx->eng;
     if (rows_cap <= 0) rows_cap = e->rows_cap > 0 ? e->rows_cap : 256;
     if (e->rows_cap > rows_cap) rows_cap = e->rows_cap;
     Net* n = e->net;
-    if (n && (n->rows_cap < rows_cap)) { tg_net_destroy(ctx); n = nullptr; }
-    const size_t P = (size_t)S * S, A = P + 1;
+    if (n && (n->rows_cap < rows_cap || n->arch != arch)) { tg_net_destroy(ctx); n = nullptr; }
+    const size_t P = (size_t)S * S, A = P + 1, Wq = (size_t)F / 4 * 2 + F;
+    const bool any_att = pol || trunk.find('A') != std::string::npos;
+    int NB = 0; for (char c : trunk) NB += c == 'R';
     if (!n) {
         n = new Net();
         e->net = n;
-        n->S = S; n->P = (int)P; n->A = (int)A; n->C = C; n->F = F; n->NB = NB; n->rows_cap = rows_cap;
+        n->S = S; n->P = (int)P; n->A = (int)A; n->C = C; n->F = F; n->NB = NB; n->rows_cap = rows_cap; n->arch = arch; n->pol_att = pol;
         n->blob_floats = n_floats;
         TG_HIP(ctx, hipMalloc((void**)&n->blob, sizeof(float) * n_floats));
         const size_t act = sizeof(float) * (size_t)rows_cap * P * F;
@@ -537,19 +657,42 @@ int tg_net_load(tg_ctx* ctx, const float* blob, size_t n_floats, int rows_cap) {
         TG_HIP(ctx, hipMalloc((void**)&n->hc, sizeof(float) * (size_t)rows_cap * P * 16));
         TG_HIP(ctx, hipMalloc((void**)&n->own, sizeof(float) * (size_t)rows_cap * P));
         TG_HIP(ctx, hipMalloc((void**)&n->frag, sizeof(float) * (size_t)(NB > 0 ? 2 * NB : 1) * 9 * F * F));
+        if (any_att) TG_HIP(ctx, hipMalloc((void**)&n->bufQ, sizeof(float) * (size_t)rows_cap * P * Wq));
+        if (pol) TG_HIP(ctx, hipMalloc((void**)&n->hca, sizeof(float) * (size_t)rows_cap * P * 16));
         const float* p = n->blob;
         auto take = [&](size_t k) { const float* q = p; p += k; return q; };
+        auto take_att = [&](AttW& a) { a.qkv.w = take(Wq * F); a.qkv.b = take(Wq); a.gamma = take(1); a.s = take(F); a.t = take(F); };
         n->stem.w = take(9 * (size_t)F * 16); n->stem.b = take(F);
         n->blocks.resize(NB);
-        for (BlockW& b : n->blocks) {
-            b.s1 = take(F); b.t1 = take(F);
-            b.c1.w = take(9 * (size_t)F * F); b.c1.b = take(F);
-            b.c2.w = take(9 * (size_t)F * F); b.c2.b = take(F);
+        int ri = 0;
+        for (char c : trunk) {
+            Layer L; L.kind = c == 'A'; L.ridx = -1; L.a = AttW{};
+            if (c == 'R') {
+                BlockW& b = n->blocks[ri]; L.ridx = ri++;
+                b.s1 = take(F); b.t1 = take(F);
+                b.c1.w = take(9 * (size_t)F * F); b.c1.b = take(F);
+                b.c2.w = take(9 * (size_t)F * F); b.c2.b = take(F);
+                b.f1 = b.f2 = nullptr;
+            } else {
+                take_att(L.a);
+            }
+            n->layers.push_back(L);
         }
         n->s_end = take(F); n->t_end = take(F);
+        if (pol) { take_att(n->patt); n->head_a.w = take(9 * 16 * (size_t)F); n->head_a.b = take(16); }
         n->head.w = take(9 * 16 * (size_t)F); n->head.b = take(16);
         n->w_vo = take(2 * P * 64); n->b_vo = take(64); n->w_v = take(64); n->b_v = take(1);
         n->w_o = take(64 * P); n->b_o = take(P); n->w_a = take(4 * P * A); n->b_a = take(A);
+        if (any_att) {
+            const size_t lds = sizeof(float) * (P * Wq + P * (P + 1));
+            if (lds <= 160 * 1024) {
+                hipError_t er = hipSuccess;
+#define TG_ATT_ATTR(SZ, FF) if (S == SZ && F == FF) er = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention<SZ, FF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                TG_ATT_ATTR(9, 32); TG_ATT_ATTR(9, 64); TG_ATT_ATTR(9, 128); TG_ATT_ATTR(9, 256);
+#undef TG_ATT_ATTR
+                TG_HIP(ctx, er);
+            }
+        }
     }
     // weight refresh (trainer.py:76-79 -> self_play.py:913) is just this copy
     TG_HIP(ctx, hipMemcpyAsync(n->blob, blob, sizeof(float) * n_floats, hipMemcpyHostToDevice, ctx->stream));
@@ -591,7 +734,7 @@ int tg_net_load(tg_ctx* ctx, const float* blob, size_t n_floats, int rows_cap) {
 void tg_net_destroy(tg_ctx* ctx) {
     if (!ctx || !ctx->eng || !ctx->eng->net) return;
     Net* n = ctx->eng->net;
-    void* ptrs[] = {n->blob, n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->frag};
+    void* ptrs[] = {n->blob, n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->frag, n->bufQ, n->hca};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t ev : n->ev) (void)hipEventDestroy(ev);
     delete n;

@@ -17,7 +17,9 @@ Blob layout (float32, in this order; `t` = ky*3+kx, convs stored [t][cout][cin] 
     stem   W[9][F][16] (cin zero-padded to 16, BN folded)      b[F]
     block  s1[F] t1[F] | W1[9][F][F] (BN2 folded) b1[F] | W2[9][F][F] b2[F]        x N
     tail   s_end[F] t_end[F]
-    head   W[9][16][F] (cout 0-1 value/own conv, 2-5 policy conv, 6-15 zero; their BNs folded)  b[16]
+    [+P]   policy-head attention: Wqkv[1.5F][F] (rows q|k|v) b[1.5F] gamma[1] s[F] t[F] | policy conv W[9][16][F] (cout 2-5) b[16]
+    head   W[9][16][F] (cout 0-1 value/own conv, 2-5 policy conv unless +P, rest zero; their BNs folded)  b[16]
+    ('A' layers in the trunk are stored like the policy-head attention block, in place of a residual block)
     fc     W_vo^T[2P][64] b[64] | w_v[64] b[1] | W_own^T[64][P] b[P] | W_act^T[4P][A] b[A]
 """
 import ctypes
@@ -46,19 +48,66 @@ def _conv_t(w):
     return np.transpose(w.reshape(co, ci, 9), (2, 0, 1))
 
 
-def pack_weights(sd, board_size, encode_dim, filters, blocks, prefix="main_network."):
-    S, C, F, NB = board_size, encode_dim, filters, blocks
+class Arch:
+    """Layer program of the trunk: kinds 'R' (pre-activation ResidualBlock, model.py:238-248) / 'A' (Self_Attention,
+    model.py:288-315) with the state_dict module name of each layer, and the name of the policy-head attention if any."""
+
+    def __init__(self, kinds, names, policy_attention=None):
+        assert len(kinds) == len(names) and set(kinds) <= {"R", "A"}
+        self.kinds, self.names, self.policy_attention = kinds, list(names), policy_attention
+
+    @property
+    def code(self):
+        return self.kinds + ("+P" if self.policy_attention else "")
+
+    @property
+    def blocks(self):
+        return self.kinds.count("R")
+
+
+def tower_arch(blocks):
+    """BASELINE.json's N-block tower."""
+    return Arch("R" * blocks, [f"res_blocks.{i}" for i in range(blocks)])
+
+
+def transgo_arch():
+    """The shipped MainNetwork (model.py:49-76): res_conv2 .. res_conv13 with Self_Attention at 3, 7, 12 and in the policy head."""
+    return Arch("RARRRARRRRAR", [f"res_conv{i}" for i in range(2, 14)], policy_attention="attention_act")
+
+
+def pack_weights(sd, board_size, encode_dim, filters, blocks=None, prefix="main_network.", arch=None):
+    S, C, F = board_size, encode_dim, filters
+    arch = arch or tower_arch(blocks)
     P, A = S * S, S * S + 1
     out = []
     g = lambda k: _np(sd[prefix + k])
+
+    def attention(name):
+        w = np.concatenate([g(name + f".{k}_conv.weight").reshape(-1, F) for k in ("query", "key", "value")], 0)
+        b = np.concatenate([g(name + f".{k}_conv.bias") for k in ("query", "key", "value")])
+        s, t = _bn(sd, prefix + name + ".bn")
+        return [w, b, g(name + ".gamma").reshape(1), s, t]          # [1.5F][F] rows q|k|v, bias, gamma, BN scale/shift
+
+    def head_conv(pairs):
+        wh = np.zeros((9, 16, F)); bh = np.zeros(16)
+        for name, lo, n in pairs:
+            s, t = _bn(sd, prefix + name + ".conv.1")
+            w = g(name + ".conv.0.weight") * s[:, None, None, None]
+            wh[:, lo:lo + n, :] = _conv_t(w)
+            bh[lo:lo + n] = g(name + ".conv.0.bias") * s + t
+        return [wh, bh]
+
     # stem: conv + BN folded
     s, t = _bn(sd, prefix + "conv1.conv.1")
     w = g("conv1.conv.0.weight") * s[:, None, None, None]
     b = g("conv1.conv.0.bias") * s + t
     wt = np.zeros((9, F, 16)); wt[:, :, :C] = _conv_t(w)
     out += [wt, b]
-    for i in range(NB):
-        pb = f"res_blocks.{i}."
+    for kind, name in zip(arch.kinds, arch.names):
+        if kind == "A":
+            out += attention(name)
+            continue
+        pb = name + "."
         s1, t1 = _bn(sd, prefix + pb + "batchnormlize_1")
         s2, t2 = _bn(sd, prefix + pb + "batchnormlize_2")
         w1 = g(pb + "conv_1.weight") * s2[:, None, None, None]
@@ -66,41 +115,42 @@ def pack_weights(sd, board_size, encode_dim, filters, blocks, prefix="main_netwo
         out += [s1, t1, _conv_t(w1), b1, _conv_t(g(pb + "conv_2.weight")), g(pb + "conv_2.bias")]
     se, te = _bn(sd, prefix + "bn_res_end")
     out += [se, te]
-    wh = np.zeros((9, 16, F)); bh = np.zeros(16)
-    for name, lo, n in (("conv_val_own", 0, 2), ("conv_act", 2, 4)):
-        s, t = _bn(sd, prefix + name + ".conv.1")
-        w = g(name + ".conv.0.weight") * s[:, None, None, None]
-        wh[:, lo:lo + n, :] = _conv_t(w)
-        bh[lo:lo + n] = g(name + ".conv.0.bias") * s + t
-    out += [wh, bh]
+    if arch.policy_attention:
+        out += attention(arch.policy_attention)
+        out += head_conv([("conv_act", 2, 4)])                      # policy conv on the attention output
+        out += head_conv([("conv_val_own", 0, 2)])                  # value/ownership conv on relu(bn_end(x))
+    else:
+        out += head_conv([("conv_val_own", 0, 2), ("conv_act", 2, 4)])
     out += [g("fc_val_own.weight").T, g("fc_val_own.bias"), g("fc_val.weight")[0], g("fc_val.bias"),
             g("fc_own.weight").T, g("fc_own.bias"), g("fc_act.weight").T, g("fc_act.bias")]
     blob = np.concatenate([np.ascontiguousarray(a, np.float64).reshape(-1) for a in out]).astype(np.float32)
-    want = _lib.load().tg_net_blob_floats(S, C, F, NB)
+    want = _lib.load().tg_net_blob_floats_arch(S, C, F, arch.code.encode())
     if blob.size != want:
-        raise ValueError(f"packed {blob.size} floats, library expects {want} for S={S} C={C} F={F} N={NB}")
+        raise ValueError(f"packed {blob.size} floats, library expects {want} for S={S} C={C} F={F} arch={arch.code}")
     return blob
 
 
-def load_into(ctx, sd, board_size, encode_dim, filters, blocks, rows_cap=0):
-    blob = pack_weights(sd, board_size, encode_dim, filters, blocks)
-    ctx.call("tg_net_load", blob.ctypes.data_as(ctypes.c_void_p), blob.size, rows_cap)
+def load_into(ctx, sd, board_size, encode_dim, filters, blocks=None, rows_cap=0, arch=None):
+    arch = arch or tower_arch(blocks)
+    blob = pack_weights(sd, board_size, encode_dim, filters, arch=arch)
+    ctx.call("tg_net_load_arch", arch.code.encode(), blob.ctypes.data_as(ctypes.c_void_p), blob.size, rows_cap)
 
 
 class HipNetwork:
     """TransGoNetwork surface (model.py:11-27) for inference: main_prediction(x) -> (policy, value, own) as NumPy."""
 
-    def __init__(self, board_size=9, encode_dim=10, filters=128, blocks=6, rows_cap=1024, device=0):
+    def __init__(self, board_size=9, encode_dim=10, filters=128, blocks=6, rows_cap=1024, device=0, arch=None):
         cfg = _lib.default_config()
         cfg.board_size, cfg.encode_dim, cfg.net_filters, cfg.net_blocks, cfg.n_games, cfg.device = \
             board_size, encode_dim, filters, blocks, 0, device
         self.ctx = _lib.Context(cfg)
         self.S, self.C, self.F, self.NB, self.rows_cap = board_size, encode_dim, filters, blocks, rows_cap
+        self.arch = arch or tower_arch(blocks)
         self._weights = None
 
     def set_weights(self, weights):                      # model.py:26-27
         self._weights = weights
-        load_into(self.ctx, weights, self.S, self.C, self.F, self.NB, self.rows_cap)
+        load_into(self.ctx, weights, self.S, self.C, self.F, rows_cap=self.rows_cap, arch=self.arch)
 
     def get_weights(self):                               # model.py:23-24
         return self._weights

@@ -113,6 +113,13 @@ typedef struct tg_mt19937 {
  * empty board, np.random.seed(seeds[g]) for the game's stream.  Leaves a root batch pending. */
 int tg_sp_reset(tg_ctx* ctx, const uint32_t* seeds, const uint8_t* mask);
 
+/* WP_MCTS.select_action prologue (self_play.py:689-700): a fresh root at the given position for every game with
+ * mask[g] != 0 (mask NULL = all); unmasked slots are parked and take no part in searches.  `states` = G blobs of
+ * tg_state_size() bytes.  RNG streams are left as they are.  Leaves a root batch pending. */
+int tg_sp_reset_from(tg_ctx* ctx, const void* states, const uint8_t* mask);
+/* Current root position of every game (G blobs), e.g. to hand a game from one engine to another. */
+int tg_sp_root_states(tg_ctx* ctx, void* states);
+
 int tg_sp_batch_rows(tg_ctx* ctx, int32_t* n_rows);                        /* rows of the pending batch */
 int tg_sp_batch_obs(tg_ctx* ctx, float* obs /*[n_rows][C][S][S]*/, int32_t n_rows);   /* env.encode of each row (self_play.py:798) */
 int tg_sp_set_eval(tg_ctx* ctx, const float* policy /*[n_rows][A]*/, const float* value /*[n_rows]*/, int32_t n_rows);

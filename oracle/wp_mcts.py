@@ -185,6 +185,13 @@ class OracleSearch:
         obs = self.env.encode(self.root.state)
         return action, pi, obs, dict(n0=n0, counts=counts, tau=tau)
 
+    def select_action(self, state):                      # self_play.py:689-703
+        self.root = Vertex(0)
+        self.root.state = state
+        self._open_root(self.root)
+        action, _, _, _ = self.search_move(selfplay=False)
+        return action
+
     def advance(self, action):                           # update_with_action, self_play.py:857-872
         nxt, done = self.env.step(self.root.state, action)
         self.root = self.root.kids[action]

@@ -102,3 +102,42 @@ def test_many_games_vs_oracle():
             assert eng.rng_state(g)[1] == rng.get_state()[2], (g, m)
     st = eng.stats()
     assert st["errors"] == 0 and st["sims"] > 0
+
+
+def test_select_action_matches_reference(golden_dir):
+    """Evaluation-mode search on the GPU (fresh root from a given position, no noise, temperature 0.12) against actions,
+    visit counts and RNG positions recorded from the reference's WP_MCTS.select_action, two agents sharing one stream."""
+    from transgo_amd.engine import SelfPlayEngine
+    from transgo_amd.environment import GoEnv
+    b = _load(golden_dir, "select_action.npz")
+    which = {"fn": evaluators.sharp}
+    eng = SelfPlayEngine(1, num_simulation=int(b["sims"]), evaluator=lambda obs: which["fn"](obs))
+    eng.reset([int(b["seed"])])               # seeds the stream; the throw-away root evaluation draws nothing
+    env = GoEnv()
+    states = env.reset_batch(1)
+    for ply, want in enumerate(b["actions"]):
+        which["fn"] = evaluators.sharp if ply % 2 == 0 else evaluators.flat
+        eng.reset_from(states)
+        eng.search(selfplay=False)
+        vis, _, _, steps, _ = eng.root_info(obs=False)
+        acts, _ = eng.choose_moves(vis, steps, selfplay=False)
+        assert (vis[0] == b["counts"][ply]).all() and acts[0] == want, ply
+        assert eng.rng_state(0)[1] == b["pos"][ply], ply
+        states, done, _ = env.step_batch(states, acts)
+
+
+def test_policy_evaluate_runs_matches_and_reports():
+    from transgo_amd import model
+    from transgo_amd.configure import Config
+    from transgo_amd.self_play import SelfPlay
+    from transgo_amd.shared_storage import SharedStorage
+    cfg = Config(num_simulation=8, max_step=14, num_features=32, num_blocks=2)
+    w_new, w_old = model.random_weights(9, 10, 32, 2, seed=1), model.random_weights(9, 10, 32, 2, seed=2)
+    st = SharedStorage({"weights": w_new, "evaluate_weights": w_old, "evaluate_score": 100}, cfg)
+    sp = SelfPlay(cfg, n_games=4)
+    ratio, info2, info3 = sp.policy_evaluate(n_games=6, shared_storage_worker=st)
+    assert 0.0 <= ratio <= 1.0 and "model player is" in info2 and info3.startswith("evaluate_score:100")
+    if ratio == 1:
+        assert st.get_info("evaluate_score") == 200 and st.get_info("evaluate_weights") is w_new
+    else:
+        assert st.get_info("evaluate_score") == 100

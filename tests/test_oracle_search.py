@@ -67,3 +67,20 @@ def test_replayed_network(golden_dir):
         ps, vs = zip(*[table[np.packbits(o.astype(np.uint8).reshape(-1)).tobytes()] for o in obs])
         return np.stack(ps), np.stack(vs)
     replay_case(blob, "real_s11_n64", lookup)
+
+
+def test_select_action_matches_reference(golden_dir):
+    """Evaluation-mode search (self_play.py:689-703, temperature 0.12, no root noise, fresh tree every move), two agents
+    sharing one RNG stream as in policy_evaluate (self_play.py:1013-1016)."""
+    b = _load(golden_dir, "select_action.npz")
+    env = OracleGoEnv()
+    rng = np.random.RandomState(int(b["seed"]))
+    bots = {1: OracleSearch(env, evaluators.sharp, rng, num_simulation=int(b["sims"])),
+            2: OracleSearch(env, evaluators.flat, rng, num_simulation=int(b["sims"]))}
+    state, _ = env.reset()
+    for ply, want in enumerate(b["actions"]):
+        bot = bots[env.getPlayer(state)]
+        a = bot.select_action(state)
+        raw = np.array([bot.root.kids[i].n if i in bot.root.kids else 0 for i in range(82)])
+        assert (raw == b["counts"][ply]).all() and a == want and rng.get_state()[2] == b["pos"][ply], ply
+        state, _ = env.step(state, a)

@@ -42,6 +42,8 @@ SIGNATURES = {
     "tg_env_query": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _u8p, _u8p, _f32p, _f32p, _f32p, _i32p, _i32p, _u8p]),
     "tg_env_show": (ctypes.c_int, [_vp, _vp]),
     "tg_sp_reset": (ctypes.c_int, [_vp, _vp, _vp]),
+    "tg_sp_reset_from": (ctypes.c_int, [_vp, _vp, _vp]),
+    "tg_sp_root_states": (ctypes.c_int, [_vp, _vp]),
     "tg_sp_batch_rows": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32)]),
     "tg_sp_batch_obs": (ctypes.c_int, [_vp, _vp, ctypes.c_int32]),
     "tg_sp_set_eval": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32]),

@@ -20,6 +20,7 @@ class Config:
         self.input_dim = self.encode_state_channels
         self.num_features = 128                  # configure.py:37
         self.num_blocks = 6                      # tower depth (BASELINE.json "N-block x F-filter")
+        self.network = "tower"                   # "tower" | "transgo" (the shipped MainNetwork with attention, model.py:49-76)
         self.concurrent_games = 4096             # boards resident on one GPU
         self.batch_size = 2048
         self.train_play_ratio = 7500 / 100000    # configure.py:61

@@ -70,33 +70,43 @@ __device__ int make_block(BoardWave<S>& bw, const BoardState<S>& st, NodeRec* ar
 
 // ---- kernels ---------------------------------------------------------------------------------------------------------------
 
+// states == nullptr: empty boards (reset_root, self_play.py:595-598).  Otherwise the root of every masked game is the given
+// position (select_action, self_play.py:689-700) and unmasked slots are parked (they take no part in searches).
 template <int S>
-__global__ __launch_bounds__(64) void k_reset(EngineDev d, const uint8_t* mask) {
+__global__ __launch_bounds__(64) void k_reset(EngineDev d, const uint8_t* mask, const BoardState<S>* states) {
     using G = Geo<S>;
     __shared__ WaveLds<S> lds;
     const int g = blockIdx.x;
-    if (mask && !mask[g]) return;
+    if (mask && !mask[g]) {
+        if (states && lane_id() == 0) { d.ctl[g].finished = 1; d.ctl[g].searching = 0; d.ctl[g].need_eval = 0; }
+        return;
+    }
     BoardWave<S> bw; bw.init(&lds);
     GameCtl c = d.ctl[g];                                             // cumulative statistics survive a reset
     c.cur = 0; c.free_slot = 0; c.n_target = 0; c.active = 0; c.n_paths = 0; c.need_eval = 0; c.root_row = 0;
     c.finished = 0; c.error = 0; c.searching = 0;
     NodeRec* arena = arena_of<S>(d.arena, g, 0, d.sc.arena_slots);
-    BoardState<S> st; state_reset(st);
+    BoardState<S> st;
+    if (states) st = states[g]; else state_reset(st);
+    const bool over = st.terminated != 0;
     bw.load_colors(st.bb[0], st.bb[1]);
     bw.analyze();
     int free_slot = 1;
-    int blk = make_block(bw, st, arena, free_slot, d.sc.arena_slots, true);
+    int blk = make_block(bw, st, arena, free_slot, d.sc.arena_slots, !over);
     int row = 0;
-    if (bw.lane == 0) row = atomicAdd(&d.counters[CNT_ROWS], 1);
-    row = __shfl(row, 0);
-    encode_planes(bw, st, d.rules, d.obs + (size_t)row * d.rules.encode_dim * G::P);
+    if (!over) {
+        if (bw.lane == 0) row = atomicAdd(&d.counters[CNT_ROWS], 1);
+        row = __shfl(row, 0);
+        encode_planes(bw, st, d.rules, d.obs + (size_t)row * d.rules.encode_dim * G::P);
+    }
     if (bw.lane == 0) {
-        NodeRec r;                                                    // Node_V(0), self_play.py:596
+        NodeRec r;                                                    // Node_V(0), self_play.py:596 / :691
         r.prior = 0.0; r.w = 0.f; r.var = 0.f; r.n = 0; r.pending = 0; r.block = blk; r.action = 0xFFFF; r.flags = 0; r.term = 0;
         arena[0] = r;
-        c.cur = 0; c.free_slot = free_slot; c.need_eval = 1; c.root_row = row; c.error = blk < 0 ? 1 : 0;
+        c.cur = 0; c.free_slot = free_slot; c.need_eval = over ? 0 : 1; c.root_row = row; c.error = blk < 0 ? 1 : 0;
+        c.finished = over ? 1 : 0;
         d.ctl[g] = c;
-        d.row_game[row] = g;
+        if (!over) d.row_game[row] = g;
     }
 }
 
@@ -438,6 +448,15 @@ __global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions
 }
 
 template <int S>
+__global__ __launch_bounds__(64) void k_root_states(EngineDev d, BoardState<S>* out) {
+    const int g = blockIdx.x;
+    if (lane_id() != 0) return;
+    GameCtl* c = &d.ctl[g];
+    NodeRec* arena = arena_of<S>(d.arena, g, c->cur, d.sc.arena_slots);
+    out[g] = hdr_of<S>(arena, arena[0].block)->st;
+}
+
+template <int S>
 __global__ __launch_bounds__(64) void k_final(EngineDev d, float* score, float* terr, int32_t* winner) {
     using G = Geo<S>;
     __shared__ WaveLds<S> lds;
@@ -552,9 +571,48 @@ int tg_sp_reset(tg_ctx* ctx, const uint32_t* seeds, const uint8_t* mask) {
         d_mask = e->d_u8;
     }
     zero_counter(ctx, CNT_ROWS);
-    TG_LAUNCH(ctx, k_reset, G, e->dev, (const uint8_t*)d_mask);
+    if (ctx->S == 9) hipLaunchKernelGGL(k_reset<9>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<9>*)nullptr);
+    else hipLaunchKernelGGL(k_reset<19>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<19>*)nullptr);
+    TG_HIP(ctx, hipGetLastError());
     e->batch_kind = BATCH_ROOTS; e->batch_ready = false;
     if (!mask) e->all_reset = true;
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TG_OK;
+}
+
+int tg_sp_reset_from(tg_ctx* ctx, const void* states, const uint8_t* mask) {
+    NEED_ENGINE(ctx);
+    if (!states) return TG_ERR_ARG;
+    Engine* e = ctx->eng;
+    const int G = e->G;
+    if (e->batch_kind != BATCH_NONE) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_reset_from: an evaluation batch is pending");
+    if (!e->all_reset) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_reset_from: call tg_sp_reset first (it seeds the RNG streams)");
+    if (ctx->env_in.reserve((size_t)G * ctx->state_bytes)) TG_FAIL(ctx, TG_ERR_HIP, "hipMalloc failed");
+    TG_HIP(ctx, hipMemcpyAsync(ctx->env_in.p, states, (size_t)G * ctx->state_bytes, hipMemcpyHostToDevice, ctx->stream));
+    uint8_t* d_mask = nullptr;
+    std::vector<uint8_t> all;
+    if (mask) { TG_HIP(ctx, hipMemcpyAsync(e->d_u8, mask, G, hipMemcpyHostToDevice, ctx->stream)); d_mask = e->d_u8; }
+    zero_counter(ctx, CNT_ROWS);
+    if (ctx->S == 9) hipLaunchKernelGGL(k_reset<9>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<9>*)ctx->env_in.p);
+    else hipLaunchKernelGGL(k_reset<19>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<19>*)ctx->env_in.p);
+    TG_HIP(ctx, hipGetLastError());
+    int32_t cnt[CNT_N];
+    int rc = read_counters(ctx, cnt);
+    if (rc) return rc;
+    e->batch_kind = BATCH_ROOTS; e->batch_ready = cnt[CNT_ROWS] == 0; e->last_rows = cnt[CNT_ROWS];
+    return TG_OK;
+}
+
+int tg_sp_root_states(tg_ctx* ctx, void* states) {
+    NEED_ENGINE(ctx);
+    if (!states) return TG_ERR_ARG;
+    Engine* e = ctx->eng;
+    const size_t bytes = (size_t)e->G * ctx->state_bytes;
+    if (ctx->env_out.reserve(bytes)) TG_FAIL(ctx, TG_ERR_HIP, "hipMalloc failed");
+    if (ctx->S == 9) hipLaunchKernelGGL(k_root_states<9>, dim3(e->G), dim3(64), 0, ctx->stream, e->dev, (BoardState<9>*)ctx->env_out.p);
+    else hipLaunchKernelGGL(k_root_states<19>, dim3(e->G), dim3(64), 0, ctx->stream, e->dev, (BoardState<19>*)ctx->env_out.p);
+    TG_HIP(ctx, hipGetLastError());
+    TG_HIP(ctx, hipMemcpyAsync(states, ctx->env_out.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return TG_OK;
 }

@@ -108,6 +108,31 @@ class SelfPlayEngine:
         else:
             self.finished[np.asarray(mask, bool)] = False
 
+    def reset_from(self, states, mask=None):
+        """Fresh roots at given positions: the first half of select_action (self_play.py:689-700).  states: [G, state_size]
+        uint8 blobs (transgo_amd.environment.GoEnv states); unmasked slots are parked."""
+        st = np.ascontiguousarray(states, np.uint8)
+        assert st.shape[0] == self.G
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self.ctx.call("tg_sp_reset_from", _ptr(st), _ptr(m))
+        self._evaluate()
+        self.ctx.call("tg_sp_expand_roots")
+        self.finished = np.zeros(self.G, bool) if mask is None else ~np.asarray(mask, bool)
+
+    def root_states(self):
+        st = np.zeros((self.G, self.ctx.state_size), np.uint8)
+        self.ctx.call("tg_sp_root_states", _ptr(st))
+        return st
+
+    def select_action(self, states, mask=None):
+        """WP_MCTS.select_action (self_play.py:689-703) for G positions at once: fresh tree, no root noise, temperature
+        0.12.  Returns the chosen actions (0 for parked slots)."""
+        self.reset_from(states, mask)
+        self.search(selfplay=False)
+        vis, _, _, steps, _ = self.root_info(obs=False)
+        actions, _ = self.choose_moves(vis, steps, selfplay=False)
+        return actions
+
     def search(self, selfplay=True, num_simulation=0):
         """The search part of get_action_probs (self_play.py:659-664)."""
         self.ctx.call("tg_sp_begin_move", 1 if selfplay else 0, num_simulation)

@@ -72,6 +72,9 @@ class BatchedSelfPlay:
         self.S = config.board_size
         self.filters = getattr(config, "num_features", 128)
         self.blocks = getattr(config, "num_blocks", 6)
+        self.device = device
+        # network layout: "tower" = BASELINE.json's N-block x F-filter net; "transgo" = the shipped MainNetwork (model.py:49-76)
+        self.arch = _model.transgo_arch() if getattr(config, "network", "tower") == "transgo" else _model.tower_arch(self.blocks)
         self.engine = SelfPlayEngine(
             n_games, board_size=self.S, num_simulation=config.num_simulation,
             parallel_readouts=config.parallel_readouts, c_puct1=config.c_puct1, c_puct2=config.c_puct2,
@@ -95,7 +98,7 @@ class BatchedSelfPlay:
         return (1000 * self.rank + g + 1000003 * int(self.games_started[g]) * max(1, self.world)) % (2 ** 32)
 
     def set_weights(self, state_dict):
-        _model.load_into(self.engine.ctx, state_dict, self.S, self.config.encode_state_channels, self.filters, self.blocks)
+        _model.load_into(self.engine.ctx, state_dict, self.S, self.config.encode_state_channels, self.filters, arch=self.arch)
 
     def _reset(self, mask=None):
         idx = range(self.G) if mask is None else np.flatnonzero(mask)
@@ -167,6 +170,63 @@ class SelfPlay:
         if w is not None and id(w) != self._weights_version:
             self.worker.set_weights(w)
             self._weights_version = id(w)
+
+    def policy_evaluate(self, n_games=10, shared_storage_worker=None, seed=0):
+        """New-vs-old evaluation matches (self_play.py:986-1040): the train model ("weights") against the evaluation model
+        ("evaluate_weights"), colours alternating game by game, every move by select_action (fresh tree, no noise,
+        temperature 0.12).  All n_games run concurrently: two engines (one per weight set) each move half of the games per
+        ply.  Returns (win_ratio, info2, info3) and promotes the weights on a clean sweep exactly as the reference does."""
+        from .environment import GoEnv
+        cfg, w = self.config, self.worker
+        arch = w.arch
+        half = (n_games + 1) // 2
+        mk = lambda: SelfPlayEngine(
+            half, board_size=cfg.board_size, num_simulation=cfg.num_simulation, parallel_readouts=cfg.parallel_readouts,
+            c_puct1=cfg.c_puct1, c_puct2=cfg.c_puct2, wu_loss=cfg.wu_loss, komi=cfg.komi, max_step=cfg.max_step,
+            encode_dim=cfg.encode_state_channels, net_blocks=w.blocks, net_filters=w.filters, device=w.device)
+        eng = {"train": mk(), "eval": mk()}
+        _model.load_into(eng["train"].ctx, _get(_call(shared_storage_worker.get_info, "weights")), cfg.board_size,
+                         cfg.encode_state_channels, w.filters, arch=arch)
+        _model.load_into(eng["eval"].ctx, _get(_call(shared_storage_worker.get_info, "evaluate_weights")), cfg.board_size,
+                         cfg.encode_state_channels, w.filters, arch=arch)
+        for k, e in enumerate(eng.values()):
+            e.reset(np.arange(half) + seed + 7919 * k)            # seeds the per-game RNG streams
+        env = GoEnv(cfg, device=w.device)
+        # game i: train model plays BLACK when i is even (self_play.py:1000,1026)
+        groups = {"A": np.arange(0, n_games, 2), "B": np.arange(1, n_games, 2)}
+        states = {g: env.reset_batch(half) for g in groups}
+        done = {g: np.arange(half) >= len(idx) for g, idx in groups.items()}
+        ply = 0
+        while not (done["A"].all() and done["B"].all()):
+            black_is_train_group = "A" if ply % 2 == 0 else "B"      # whose train model is to move at this ply
+            for who, grp in (("train", black_is_train_group), ("eval", "B" if black_is_train_group == "A" else "A")):
+                live = ~done[grp]
+                if not live.any():
+                    continue
+                acts = eng[who].select_action(states[grp], live)
+                nxt, d, _ = env.step_batch(states[grp], np.where(live, acts, cfg.board_size ** 2))
+                states[grp][live] = nxt[live]
+                done[grp] |= d & live
+            ply += 1
+        win_num = 0
+        info2 = None
+        for grp, colour in (("A", 1), ("B", 2)):
+            n = len(groups[grp])
+            score = env.query_batch(states[grp][:n], score=True)["score"] if n else []
+            for k in range(n):
+                winner = 1 if score[k] > 0 else 2                     # environment.py:118-119
+                win_num += int(winner == colour)
+                info2 = "simulate round: {},  winer is : {},  model player is : {}\n".format(int(groups[grp][k]) + 1, winner, colour)
+        lose_num = n_games - win_num
+        evaluate_score = _get(_call(shared_storage_worker.get_info, "evaluate_score"))
+        info3 = "evaluate_score:{}, win: {}, lose: {}\n".format(evaluate_score, win_num, lose_num)
+        win_ratio = win_num / n_games
+        if win_ratio == 1:                                             # self_play.py:1035-1038
+            _call(shared_storage_worker.set_info, "evaluate_score", evaluate_score + 100)
+            _call(shared_storage_worker.set_info, "evaluate_weights", _get(_call(shared_storage_worker.get_info, "weights")))
+        for e in eng.values():
+            e.close()
+        return win_ratio, info2, info3
 
     def continuous_self_play(self, shared_storage_worker, mem, max_moves=None):
         moves = 0

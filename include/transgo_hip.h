@@ -6,7 +6,7 @@
  * the library never keeps a caller pointer after a call returns.  All functions return 0 on success or a negative
  * tg_status; tg_last_error() gives the message.  A context is single-owner (one host thread, one GPU).
  *
- * Three groups:
+ * Four groups (the fourth = the reference's own 15 names, for binding-compatibility):
  *   1. tg_env_*   batched form of the 15 extern "C" functions of GoEnv/cpp_src/go_env.h:24-70 over opaque state blobs
  *                 (what GoEnv/environment.py:42-90 binds through ctypes today).
  *   2. tg_sp_*    the batched self-play engine: G concurrent games, WP_MCTS (self_play.py:575-875) as HIP tree
@@ -17,6 +17,7 @@
 #ifndef TRANSGO_HIP_H_
 #define TRANSGO_HIP_H_
 
+#include <stdbool.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -182,6 +183,31 @@ uint32_t tg_host_mt_next32(tg_mt19937* s);
 double tg_host_mt_random_sample(tg_mt19937* s);                     /* random_sample(): the draw inside choice(A, p=) (self_play.py:683) */
 int32_t tg_host_mt_choice_index(tg_mt19937* s, int32_t k);          /* index drawn by choice(list of k) (self_play.py:709) */
 int tg_host_mt_dirichlet(tg_mt19937* s, double alpha, int32_t n, double* out);   /* dirichlet([alpha]*n) (self_play.py:93) */
+
+
+/* ---- 4. the reference engine's own 15 entry points (GoEnv/cpp_src/go_env.h:24-70), same names and signatures -------------
+ * One process-wide context (the reference keeps its configuration in file-static variables, go_env.cc:9-12); every call is
+ * the batched GPU entry point with n = 1.  `State` is any caller buffer of at least tg_state_size() bytes -- the
+ * reference's 1188-byte GoState / Python's 1196-byte c_GoState (environment.py:17-29) qualify, so GoEnv/environment.py binds
+ * this library unchanged.  Board size: 9, or 19 with TRANSGO_BOARD_SIZE=19 in the environment (go_comm.h:20 is compile-time
+ * in the reference).  Coord = int16_t, Stone = uint8_t (go_comm.h:13-15). */
+#ifndef TRANSGO_NO_GOENV_NAMES
+bool Init(int history_dim, int encode_dim, int max_step, float komi);        /* go_env.h:30 */
+bool Reset(void* state);                                                      /* go_env.h:33 */
+bool Step(const void* state, void* next_state, int16_t action);              /* go_env.h:37 */
+bool Step_(void* state, int16_t action);                                      /* go_env.h:38 */
+bool checkAction(const void* state, int16_t action);                          /* go_env.h:42 */
+bool isTerminated(const void* state);                                         /* go_env.h:45 */
+bool Encode(const void* state, float* encode_state);                          /* go_env.h:48 */
+float getScore(const void* state);                                            /* go_env.h:51 */
+float getTerritory(const void* state, float* territory);                      /* go_env.h:54 */
+int getLegalAction(const void* state, int* actions);                          /* go_env.h:57 */
+int getLegalNoEye(const void* state, int* actions);                           /* go_env.h:60 */
+void Show(const void* state);                                                 /* go_env.h:63 */
+uint8_t getPlayer(const void* state);                                         /* go_env.h:66 */
+int getStep(const void* state);                                               /* go_env.h:69 */
+void getSubEncode(int* encode_state, int* sub_encode_state, int sub_board_size, int encode_state_channels, int cut_num);  /* go_env.h:70 */
+#endif
 
 #ifdef __cplusplus
 }

@@ -49,3 +49,22 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "go_oracle" not in txt, f
+
+
+def test_reference_go_env_symbols_exported():
+    """The 15 names of GoEnv/cpp_src/go_env.h:24-70, so the reference's own environment.py can bind this library."""
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in ("Init Reset Step Step_ checkAction isTerminated Encode getScore getTerritory getLegalAction getLegalNoEye "
+              "Show getPlayer getStep getSubEncode").split():
+        assert hasattr(lib, n), n
+
+
+def test_get_sub_encode_crops_like_the_reference():
+    """getSubEncode is host-side word movement (board.cc:1166-1271): 4 corner windows then the centre."""
+    import numpy as np
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    enc = np.arange(10 * 81, dtype=np.float32).reshape(10, 9, 9)
+    sub = np.zeros((5, 10, 7, 7), np.float32)
+    lib.getSubEncode(enc.ctypes.data_as(ctypes.c_void_p), sub.ctypes.data_as(ctypes.c_void_p), 7, 10, 5)
+    assert (sub[0] == enc[:, :7, :7]).all() and (sub[1] == enc[:, :7, 2:]).all() and (sub[2] == enc[:, 2:, :7]).all()
+    assert (sub[3] == enc[:, 2:, 2:]).all() and (sub[4] == enc[:, 1:8, 1:8]).all()

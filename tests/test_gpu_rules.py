@@ -82,3 +82,51 @@ def test_no_gpu_fallback_symbols():
     from transgo_amd import environment
     src = inspect.getsource(environment)
     assert "oracle" not in src.replace("no CPU", "")
+
+
+def test_reference_ctypes_binding_works_unchanged(golden_dir):
+    """Bind the library exactly the way GoEnv/environment.py:42-90 does (same restype/argtypes, a 1196-byte c_GoState-sized
+    buffer per state) and replay crafted + random fixture games through Init/Reset/Step/getLegalAction/Encode/getTerritory."""
+    import ctypes
+    from numpy.ctypeslib import ndpointer
+    from transgo_amd import _lib
+    lib = ctypes.cdll.LoadLibrary(_lib.LIB_PATH)
+    State = ctypes.c_char * 1196
+    lib.Init.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float]
+    lib.Init(1, 10, 120, 7.5)
+    lib.Step.argtypes = [ctypes.POINTER(State), ctypes.POINTER(State), ctypes.c_int]; lib.Step.restype = ctypes.c_bool
+    lib.Reset.argtypes = [ctypes.POINTER(State)]
+    lib.Encode.argtypes = [ctypes.POINTER(State), ndpointer(ctypes.c_float)]
+    lib.getTerritory.argtypes = [ctypes.POINTER(State), ndpointer(ctypes.c_float)]; lib.getTerritory.restype = ctypes.c_float
+    lib.getLegalAction.argtypes = [ctypes.POINTER(State), ndpointer(ctypes.c_int)]; lib.getLegalAction.restype = ctypes.c_int
+    lib.getPlayer.argtypes = [ctypes.POINTER(State)]; lib.getPlayer.restype = ctypes.c_int
+    lib.getStep.argtypes = [ctypes.POINTER(State)]; lib.getStep.restype = ctypes.c_int
+
+    class Env:                                            # the method bodies of environment.py:92-173, verbatim in spirit
+        def reset(self):
+            s = State(); lib.Reset(s); return s, False
+        def step(self, state, action):
+            n = State(); done = lib.Step(state, n, action); return n, done
+        def encode(self, state):
+            e = np.zeros([10, 9, 9], dtype="float32"); lib.Encode(state, e); return e
+        def getLegalAction(self, state):
+            buf = np.zeros([82], dtype="int32"); n = lib.getLegalAction(state, buf); acts = buf[:n]
+            return acts if n == 1 else [a for a in acts if a != 81]
+        def getLegalNoEye(self, state):
+            return henv_noeye(state)
+        def getPlayer(self, state): return lib.getPlayer(state)
+        def getStep(self, state): return lib.getStep(state)
+        def getScoreAndTerritory(self, state):
+            t = np.zeros([81], dtype="float32"); s = lib.getTerritory(state, t); return s, t
+        def getScore(self, state): return self.getScoreAndTerritory(state)[0]
+        def checkAction(self, state, a): return bool(lib.checkAction(state, ctypes.c_int(a)))
+
+    lib.getLegalNoEye.argtypes = [ctypes.POINTER(State), ndpointer(ctypes.c_int)]; lib.getLegalNoEye.restype = ctypes.c_int
+    lib.checkAction.argtypes = [ctypes.POINTER(State), ctypes.c_int]; lib.checkAction.restype = ctypes.c_bool
+
+    def henv_noeye(state):
+        buf = np.zeros([82], dtype="int32"); n = lib.getLegalNoEye(state, buf); return buf[:n]
+    blob = rules_replay.load(golden_dir)
+    crafted = set(range(int(blob["n_random"]), int(blob["n_random"]) + len(blob["crafted_names"])))
+    n = rules_replay.replay(Env(), blob, games=crafted | {0, 1, 2})
+    assert n > 300

@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--sims", type=int, default=400)
     ap.add_argument("--filters", type=int, default=128)
     ap.add_argument("--blocks", type=int, default=6)
+    ap.add_argument("--board", type=int, default=9, help="board edge (9 = BASELINE configs[1]; 19 = configs[3])")
+    ap.add_argument("--max-step", type=int, default=0, help="ply limit (default 120 at 9x9, 450 at 19x19)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     a = ap.parse_args()
@@ -91,25 +93,32 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.board == 9:
         cpu = cpu_baseline(a.cpu_seconds, a.sims, a.filters, a.blocks)      # before any GPU context exists
 
     import torch
     import torch.distributed as dist
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local if os.environ.get("TRANSGO_DIST_BACKEND", "nccl") == "nccl" else 0)
     torch.cuda.set_device(dev)
+    backend = os.environ.get("TRANSGO_DIST_BACKEND", "nccl")        # "gloo": rehearsal of the N>1 path with several ranks on one GPU
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    cdev = dev if backend == "nccl" else torch.device("cpu")          # where collective payloads live
 
     from transgo_amd import model
     from transgo_amd.configure import Config
     from transgo_amd.distributed import gather_records
     from transgo_amd.self_play import BatchedSelfPlay
 
-    cfg = Config(num_simulation=a.sims, num_features=a.filters, num_blocks=a.blocks)
-    sp = BatchedSelfPlay(cfg, a.games, device=local, rank=rank, world=world)
-    sp.set_weights(model.random_weights(9, 10, a.filters, a.blocks, seed=1234))
+    S = a.board
+    cfg = Config(num_simulation=a.sims, num_features=a.filters, num_blocks=a.blocks, board_size=S,
+                 max_step=a.max_step or (120 if S == 9 else 450))
+    sp = BatchedSelfPlay(cfg, a.games, device=local if backend == "nccl" else 0, rank=rank, world=world)
+    sp.set_weights(model.random_weights(S, 10, a.filters, a.blocks, seed=1234))
     sp.start()
 
     def barrier():
@@ -120,7 +129,7 @@ def main():
     gathered = 0
     for _ in range(a.warmup):
         fin = sp.step()
-        gathered += len(gather_records(fin, 9, 10, 0, dev))
+        gathered += len(gather_records(fin, S, 10, 0, cdev))
     eng = sp.engine
     eng.ctx.call("tg_prof_enable", 1, 8192)
     st0 = eng.stats()
@@ -128,7 +137,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         fin = sp.step()
-        gathered += len(gather_records(fin, 9, 10, 0, dev))
+        gathered += len(gather_records(fin, S, 10, 0, cdev))
     barrier()
     dt = time.perf_counter() - t0
     st1 = eng.stats()
@@ -136,8 +145,8 @@ def main():
     eng.ctx.call("tg_prof_read", ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(fl))
 
     sims = st1["sims"] - st0["sims"]; evals = st1["evals"] - st0["evals"]; depth = st1["depth_sum"] - st0["depth_sum"]
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    s = torch.tensor([float(sims), float(evals), float(depth)], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    s = torch.tensor([float(sims), float(evals), float(depth)], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
@@ -146,18 +155,18 @@ def main():
     if rank == 0:
         value = sims_all / dt
         conv_tflops = (fl.value / (ms.value * 1e-3)) / 1e12 if ms.value > 0 else 0.0
-        fpl = flops_per_leaf(9, 10, a.filters, a.blocks)
+        fpl = flops_per_leaf(S, 10, a.filters, a.blocks)
         line = {
             "metric": "MCTS simulations/sec", "value": round(value, 1), "unit": "sims/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"9x9 Go self-play, {a.sims} sims/move, {a.blocks}-block x {a.filters}-filter tower, "
+            "config": {"workload": f"{S}x{S} Go self-play, {a.sims} sims/move, {a.blocks}-block x {a.filters}-filter tower, "
                                    f"{a.games} concurrent boards per GPU", "boards_per_gpu": a.games,
                        "parallelism": f"games sharded over {world} GPU(s), no data-path collective",
                        "step": "one move of every board (search + move selection + re-root + gather of finished games)"},
             "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": PEAK_F32_MATRIX_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(conv_tflops / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
-                         "kernel": f"k_conv3x3<9,{a.filters},{a.filters}> (fp32 MFMA 16x16x4 implicit GEMM)",
+                         "kernel": f"k_conv3x3<{S},{a.filters},{a.filters}> (fp32 MFMA 16x16x4 implicit GEMM)",
                          "launches": int(nl.value), "avg_launch_ms": round(ms.value / max(1, nl.value), 4)},
             "cpu_baseline": cpu,
             "extra": {"leaves_per_s": round(evals_all / dt, 1), "mean_depth": round(depth_all / max(1.0, sims_all), 3),

@@ -100,6 +100,11 @@ class BatchedSelfPlay:
     def set_weights(self, state_dict):
         _model.load_into(self.engine.ctx, state_dict, self.S, self.config.encode_state_channels, self.filters, arch=self.arch)
 
+    def set_weights_blob(self, blob):
+        import ctypes
+        blob = np.ascontiguousarray(blob, np.float32)
+        self.engine.ctx.call("tg_net_load_arch", self.arch.code.encode(), blob.ctypes.data_as(ctypes.c_void_p), blob.size, 0)
+
     def _reset(self, mask=None):
         idx = range(self.G) if mask is None else np.flatnonzero(mask)
         seeds = np.zeros(self.G, np.uint32)
@@ -166,10 +171,32 @@ class SelfPlay:
         self._weights_version = None
 
     def _refresh_weights(self, shared_storage_worker):
-        w = _get(_call(shared_storage_worker.get_info, "weights"))              # self_play.py:913
-        if w is not None and id(w) != self._weights_version:
-            self.worker.set_weights(w)
-            self._weights_version = id(w)
+        """self_play.py:913.  With several ranks, rank 0 asks the storage actor and every other rank receives the packed
+        blob by one RCCL broadcast (transgo_amd.distributed.broadcast_weights)."""
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        w = None
+        if not multi or dist.get_rank() == 0:
+            w = _get(_call(shared_storage_worker.get_info, "weights"))
+        if not multi:
+            if w is not None and id(w) != self._weights_version:
+                self.worker.set_weights(w)
+                self._weights_version = id(w)
+            return
+        import torch
+        from .distributed import broadcast_weights
+        wk = self.worker
+        dev = torch.device("cuda", wk.device) if dist.get_backend() == "nccl" else torch.device("cpu")
+        changed = torch.tensor([int(w is not None and id(w) != self._weights_version)], device=dev)
+        dist.broadcast(changed, src=0)
+        if not int(changed.item()):
+            return
+        n = _model._lib.load().tg_net_blob_floats_arch(wk.S, wk.config.encode_state_channels, wk.filters, wk.arch.code.encode())
+        blob = _model.pack_weights(w, wk.S, wk.config.encode_state_channels, wk.filters, arch=wk.arch) if w is not None \
+            else np.zeros(n, np.float32)
+        blob = broadcast_weights(blob, src=0, device=dev)
+        wk.set_weights_blob(blob)
+        self._weights_version = id(w) if w is not None else object()
 
     def policy_evaluate(self, n_games=10, shared_storage_worker=None, seed=0):
         """New-vs-old evaluation matches (self_play.py:986-1040): the train model ("weights") against the evaluation model

@@ -63,7 +63,6 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 #define TG_WP_CC 16          // input channels per activation slice of k_conv3x3_wp
 #endif
 
-constexpr int TM = 128;         // output rows (positions) per workgroup of k_conv3x3
 
 template <int S>
 __global__ __launch_bounds__(256) void k_obs_to_rows(const float* __restrict__ obs, float* __restrict__ x0, int rows, int C) {
@@ -80,12 +79,13 @@ __global__ __launch_bounds__(256) void k_obs_to_rows(const float* __restrict__ o
 
 // EPI 0: out = relu(acc + bias)      EPI 1: out = acc + bias + res      EPI 2: out = acc + bias
 // NTAP 9: 3x3 convolution with zero padding; NTAP 1: 1x1 convolution (the q/k/v projections of Self_Attention, model.py:294-296)
-template <int S, int CIN, int COUT, bool PRO, int EPI, int NTAP = 9>
-__global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, float* __restrict__ out,
+template <int S, int CIN, int COUT, bool PRO, int EPI, int NTAP = 9, int NPT = 2>
+__global__ __launch_bounds__(256, (NPT > 2 ? 2 : 1)) void k_conv3x3(const float* __restrict__ in, float* __restrict__ out,
                                                  const float* __restrict__ res, const float* __restrict__ Wt,
                                                  const float* __restrict__ bias, const float* __restrict__ ps,
                                                  const float* __restrict__ pt, int M) {
     constexpr int P = S * S, HALO = NTAP == 9 ? S + 1 : 0;
+    constexpr int TM = 64 * NPT;                    // output rows per workgroup: 4 waves x NPT position tiles x 16
     constexpr int CC = CIN < 32 ? CIN : 32;         // input channels staged per pass
     constexpr int RS = CC + 4;                      // LDS row stride (floats)
     constexpr int NROW = TM + 2 * HALO;
@@ -97,10 +97,10 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, f
     const int j = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.x * TM;
 
-    unsigned vmask[2];
+    unsigned vmask[NPT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int m = m0 + (wave * 2 + t) * 16 + j;
+    for (int t = 0; t < NPT; ++t) {
+        const int m = m0 + (wave * NPT + t) * 16 + j;
         unsigned mk = 0;
         if (m < M) {
             const int p = m % P, x = p % S, y = p / S;
@@ -113,9 +113,11 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, f
         }
         vmask[t] = mk;
     }
-    f32x4 acc[CT][2];
+    f32x4 acc[CT][NPT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) { acc[ct][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ct][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int t = 0; t < NPT; ++t) acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // Software pipeline: the global loads of stage s+1 (one tap's weights; every 9th stage also the next 32-channel
     // slice of the activation tile) are issued before the MFMA block of stage s and land in registers while it runs;
@@ -185,10 +187,10 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, f
             const int toff = NTAP == 9 ? (tap / 3 - 1) * S + (tap % 3 - 1) : 0;
 #pragma unroll
             for (int sub = 0; sub < CC / 16; ++sub) {
-                f32x4 b[2];
+                f32x4 b[NPT];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int r = (wave * 2 + t) * 16 + j + HALO + toff;
+                for (int t = 0; t < NPT; ++t) {
+                    const int r = (wave * NPT + t) * 16 + j + HALO + toff;
                     b[t] = *reinterpret_cast<const f32x4*>(&xs[r * RS + sub * 16 + kq * 4]);
                     if (!((vmask[t] >> tap) & 1)) b[t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
@@ -196,18 +198,18 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, f
                 for (int ct = 0; ct < CT; ++ct) {
                     const f32x4 a = *reinterpret_cast<const f32x4*>(&ws[(ct * 16 + j) * RS + sub * 16 + kq * 4]);
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[0][s], acc[ct][0], 0, 0, 0);
-                        acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[1][s], acc[ct][1], 0, 0, 0);
-                    }
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int t = 0; t < NPT; ++t)
+                            acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[t][s], acc[ct][t], 0, 0, 0);
                 }
             }
         }
     }
     // D tile: row (lane>>4)*4 + r = cout, column lane&15 = position
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int m = m0 + (wave * 2 + t) * 16 + j;
+    for (int t = 0; t < NPT; ++t) {
+        const int m = m0 + (wave * NPT + t) * 16 + j;
         if (m >= M) continue;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
@@ -495,7 +497,11 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
     constexpr int P = S * S;
     hipStream_t st = ctx->stream;
     const int M = rows * P;
-    const int grid = (M + TM - 1) / TM;
+    const int grid = (M + 127) / 128;                 // stem / head / 1x1 convs: 128 rows per workgroup
+    // position tiles per wave in the F->F convs (workgroup = 64*NPT rows): 3 while the accumulators (F/16*NPT*4 registers)
+    // still leave room for two waves per SIMD, else 2.  Measured at F=128: 128.0 -> 132.3 TFLOP/s.
+    constexpr int NPT = F <= 128 ? 3 : 2;
+    const int grid_f = (M + 64 * NPT - 1) / (64 * NPT);
     // k_conv3x3_wp: independent waves of (16*WP_NPT rows) x (16*WP_CTW couts); 4 waves per workgroup
     constexpr int WP_CTW = (F / 16) < TG_WP_CTW ? (F / 16) : TG_WP_CTW;
     constexpr int WP_NPT = TG_WP_ACC / WP_CTW;
@@ -536,7 +542,7 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
           hipLaunchKernelGGL((k_conv3x3_wp<S, F, true, 0, WP_NPT, WP_CTW>), dim3(grid_w), dim3(256), 0, st, (const float*)x, n->bufH,
                              (const float*)nullptr, b.f1, b.c1.b, b.s1, b.t1, M);
 #else
-          hipLaunchKernelGGL((k_conv3x3<S, F, F, true, 0>), dim3(grid), dim3(256), 0, st, (const float*)x, n->bufH,
+          hipLaunchKernelGGL((k_conv3x3<S, F, F, true, 0, 9, NPT>), dim3(grid_f), dim3(256), 0, st, (const float*)x, n->bufH,
                              (const float*)nullptr, b.c1.w, b.c1.b, b.s1, b.t1, M);
 #endif
         }
@@ -545,7 +551,7 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
           hipLaunchKernelGGL((k_conv3x3_wp<S, F, false, 1, WP_NPT, WP_CTW>), dim3(grid_w), dim3(256), 0, st, (const float*)n->bufH, y,
                              (const float*)x, b.f2, b.c2.b, (const float*)nullptr, (const float*)nullptr, M);
 #else
-          hipLaunchKernelGGL((k_conv3x3<S, F, F, false, 1>), dim3(grid), dim3(256), 0, st, (const float*)n->bufH, y,
+          hipLaunchKernelGGL((k_conv3x3<S, F, F, false, 1, 9, NPT>), dim3(grid_f), dim3(256), 0, st, (const float*)n->bufH, y,
                              (const float*)x, b.c2.w, b.c2.b, (const float*)nullptr, (const float*)nullptr, M);
 #endif
         }

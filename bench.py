@@ -153,6 +153,13 @@ def main():
     dt = float(t.item()); sims_all, evals_all, depth_all = [float(x) for x in s.tolist()]
 
     if rank == 0:
+        # HBM bytes per launch of the dominant kernel come from PMC passes (separate rocprofv3 runs, committed under profiles/);
+        # they only describe the configuration they were collected on
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if os.path.exists(tfile) and (S, a.filters, a.games) == (9, 128, 4096):
+            with open(tfile) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch_mean")
         value = sims_all / dt
         conv_tflops = (fl.value / (ms.value * 1e-3)) / 1e12 if ms.value > 0 else 0.0
         fpl = flops_per_leaf(S, 10, a.filters, a.blocks)
@@ -165,7 +172,8 @@ def main():
                        "parallelism": f"games sharded over {world} GPU(s), no data-path collective",
                        "step": "one move of every board (search + move selection + re-root + gather of finished games)"},
             "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": PEAK_F32_MATRIX_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(conv_tflops / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(conv_tflops / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": traffic,
+                         "traffic_note": "HBM bytes per full-batch launch, FETCH_SIZE x2 + WRITE_SIZE (profiles/r1_pmc_traffic.json)",
                          "kernel": f"k_conv3x3<{S},{a.filters},{a.filters}> (fp32 MFMA 16x16x4 implicit GEMM)",
                          "launches": int(nl.value), "avg_launch_ms": round(ms.value / max(1, nl.value), 4)},
             "cpu_baseline": cpu,

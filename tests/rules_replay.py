@@ -11,12 +11,14 @@ def unpack(bits, n):
     return np.unpackbits(bits)[:n]
 
 
-def load(golden_dir):
-    with np.load(os.path.join(golden_dir, "rules_s9.npz")) as z:      # NpzFile decompresses on every [] access
+def load(golden_dir, name="rules_s9.npz"):
+    with np.load(os.path.join(golden_dir, name)) as z:      # NpzFile decompresses on every [] access
         return {k: z[k] for k in z.files}
 
 
 def replay(env, blob, games=None):
+    S = int(blob["size"]) if "size" in blob else 9
+    P9 = S * S
     game = blob["game"]
     n_rec = len(game)
     checked = 0
@@ -36,8 +38,8 @@ def replay(env, blob, games=None):
             noeye = np.zeros(P9 + 1, np.uint8); noeye[np.asarray(env.getLegalNoEye(state), dtype=np.int64)] = 1
             assert (noeye == unpack(blob["noeye"][r], P9 + 1)).all(), ("noeye", g, r - i)
             obs = env.encode(state)
-            assert obs.dtype == np.float32 and obs.shape == (10, 9, 9)
-            assert (obs.reshape(-1).astype(np.uint8) == unpack(blob["obs"][r], 810)).all(), ("obs", g, r - i)
+            assert obs.dtype == np.float32 and obs.shape == (10, S, S)
+            assert (obs.reshape(-1).astype(np.uint8) == unpack(blob["obs"][r], 10 * P9)).all(), ("obs", g, r - i)
             assert env.getPlayer(state) == blob["player"][r] and env.getStep(state) == blob["step"][r]
             score, terr = env.getScoreAndTerritory(state)
             assert np.float32(score) == blob["score"][r], ("score", g, r - i)

@@ -130,3 +130,13 @@ def test_reference_ctypes_binding_works_unchanged(golden_dir):
     crafted = set(range(int(blob["n_random"]), int(blob["n_random"]) + len(blob["crafted_names"])))
     n = rules_replay.replay(Env(), blob, games=crafted | {0, 1, 2})
     assert n > 300
+
+
+def test_rules_fixture_19x19_gpu(golden_dir):
+    from transgo_amd.environment import GoEnv
+    blob = rules_replay.load(golden_dir, "rules_s19.npz")
+
+    class C: pass
+    c = C(); c.board_size = 19; c.max_step = int(blob["max_step"]); c.komi = 7.5; c.encode_state_channels = 10
+    n = rules_replay.replay(GoEnv(c), blob)
+    assert n > 1500

@@ -78,3 +78,10 @@ def test_against_compiled_reference_19x19_logic_is_size_generic():
             b, d2 = env.step(b, act)
             assert bool(d1) == d2
             done = d2
+
+
+def test_rules_fixture_19x19(golden_dir):
+    """19x19 games recorded from a 19x19 build of the reference engine (tests/golden/gen_rules19.py)."""
+    blob = rules_replay.load(golden_dir, "rules_s19.npz")
+    n = rules_replay.replay(OracleGoEnv(board_size=19, max_step=int(blob["max_step"])), blob)
+    assert n > 1500

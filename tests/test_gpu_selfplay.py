@@ -47,3 +47,51 @@ def test_continuous_self_play_feeds_storage():
     assert mem.info()["index"] == 5 * 6 * 8
     s, p, z, o = map(np.stack, zip(*mem.sample(32)))     # trainer.py:49
     assert s.shape == (32, 10, 9, 9) and p.shape == (32, 82) and set(np.unique(z)) <= {-1.0, 1.0} and o.shape == (32, 81)
+
+
+def test_end_to_end_visit_counts_with_the_real_network():
+    """Whole engine (tree kernels + MFMA network) against the CPU oracle driving the fp32 torch tower with the same weights
+    and seeds.  The two networks differ by ~1e-8, so visit counts can only diverge at near-exact PUCT ties: require the great
+    majority of (game, move) visit-count vectors -- and every game's first move -- to be identical."""
+    import torch
+    from oracle.go_oracle import OracleGoEnv
+    from oracle.net import TowerNetwork
+    from oracle.wp_mcts import OracleSearch
+    from transgo_amd import model
+    from transgo_amd.engine import SelfPlayEngine
+    torch.set_num_threads(4)
+    G, sims, moves, F, NB = 12, 48, 4, 32, 2
+    sd = model.random_weights(9, 10, F, NB, seed=77)
+    net = TowerNetwork(9, 10, F, NB).eval()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+
+    def ev(obs):
+        with torch.no_grad():
+            p, v, _ = net.main_prediction(torch.from_numpy(obs))
+        return p.numpy(), v.numpy()
+    eng = SelfPlayEngine(G, num_simulation=sims, net_blocks=NB, net_filters=F)
+    model.load_into(eng.ctx, sd, 9, 10, F, NB)
+    seeds = np.arange(500, 500 + G)
+    eng.reset(seeds)
+    orcs = [OracleSearch(OracleGoEnv(), ev, np.random.RandomState(int(s)), num_simulation=sims) for s in seeds]
+    same, total, alive = 0, 0, np.ones(G, bool)
+    for m in range(moves):
+        eng.search()
+        vis, rn, pl, st, ob = eng.root_info()
+        acts, pis = eng.choose_moves(vis, st)
+        for g, o in enumerate(orcs):
+            if not alive[g]:
+                continue
+            a, pi, obs, info = o.search_move()
+            raw = np.array([o.root.kids[i].n if i in o.root.kids else 0 for i in range(82)])
+            ok = (raw == vis[g]).all() and a == acts[g]
+            total += 1; same += int(ok)
+            if m == 0:
+                assert ok, (g, "first move must match exactly")
+            if not ok:
+                alive[g] = False                 # trajectories have split; stop comparing this game
+            else:
+                o.advance(a)
+        eng.play(acts)
+    print(f"identical visit-count vectors: {same}/{total}")
+    assert same >= 0.85 * total

@@ -175,6 +175,19 @@ int tg_net_predict(tg_ctx* ctx, const float* obs, int n_rows, float* policy, flo
 int tg_prof_enable(tg_ctx* ctx, int on, int max_launches);
 int tg_prof_read(tg_ctx* ctx, double* conv_ms, int64_t* conv_launches, double* conv_flops);
 
+/* ---- device-resident replay store + batch sampler (replaces replay_buffer.py:30-47 + the stacking of trainer.py:46-54) ----
+ * Positions are stored once, un-augmented and compact; entry e of the reference's ring of augmented tuples is
+ * (position e/8, symmetry e%8) in the reference's append order (self_play.py:943-965: for i in 1..4: rot90(i), fliplr of
+ * that).  tg_replay_sample materialises entries as the four float32 arrays the trainer feeds the network. */
+typedef struct tg_replay tg_replay;
+int tg_replay_create(tg_ctx* ctx, int capacity_positions, tg_replay** out);
+void tg_replay_destroy(tg_replay* rp);
+int tg_replay_append(tg_replay* rp, const uint32_t* obs_bits /*[n][ceil(C*S*S/32)]*/, const int32_t* counts /*[n][A]*/,
+                     const float* z /*[n]*/, const int8_t* own /*[n][S*S]*/, int n);
+int tg_replay_info(const tg_replay* rp, long long* entries, long long* index, int* full);
+int tg_replay_sample(tg_replay* rp, const long long* entry /*[B]*/, int B, float* state /*[B][C][S][S]*/, float* pi /*[B][A]*/,
+                     float* z /*[B]*/, float* own /*[B][S*S]*/, int device_out);
+
 /* ---- 3. host-only NumPy-legacy MT19937 helpers ------------------------------------------------------------------------
  * Same stream as np.random.RandomState: key/pos are get_state()[1] / get_state()[2].  No GPU needed. */
 

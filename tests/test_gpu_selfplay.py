@@ -95,3 +95,37 @@ def test_end_to_end_visit_counts_with_the_real_network():
         eng.play(acts)
     print(f"identical visit-count vectors: {same}/{total}")
     assert same >= 0.85 * total
+
+
+def test_device_replay_sampler_equals_reference_buffer_plus_trainer_stacking():
+    """tg_replay_sample against the reference data path: 8-fold augmented tuples appended in order into the object ring
+    (replay_buffer.py:30-34), sampled by index, np.stack'ed and converted to float32 as trainer.py:46-54 does."""
+    import torch
+    from transgo_amd.configure import Config
+    from transgo_amd.replay_buffer import DeviceReplayMemory, ReplayMemory_Random
+    from transgo_amd.self_play import GameRecord, game_targets
+    cfg = Config(buffer_size=8 * 64)
+    rng = np.random.RandomState(5)
+    host = ReplayMemory_Random(cfg)
+    dev = DeviceReplayMemory(cfg, capacity_positions=64)
+    for g in range(5):                                    # 5 games x 17 positions = 85 > 64: exercises the ring wrap
+        r = GameRecord(g)
+        for m in range(17):
+            r.observations.append((rng.rand(10, 9, 9) < 0.25).astype(np.float32))
+            v = rng.randint(0, 30, 82).astype(np.int32); v[rng.randint(82)] += 5; v[rng.randint(82)] = 1
+            r.visits.append(v)
+            c = np.where(v == 1, 0, v); r.pis.append(c / np.sum(c)); r.players.append(1 + m % 2)
+        r.winner = 1 + g % 2; r.territory = rng.randint(-1, 2, 81).astype(np.float32)
+        for t in game_targets(r.observations, r.pis, r.players, r.winner, r.territory, 9):
+            host.append(*t)
+        dev.append_game(r)
+    assert dev.info()["entries"] == 64 * 8 and dev.info()["full"] and host.info()["full"]
+    assert dev.info()["index"] == host.info()["index"]
+    idx = rng.choice(64 * 8, 200, replace=False)
+    s, p, z, o = map(np.stack, zip(*host.data[idx]))     # trainer.py:49
+    s, p, z, o = (torch.FloatTensor(a).numpy() for a in (s, p, z, o))
+    ds, dp, dz, do = dev.sample_entries(idx)
+    assert np.array_equal(ds, s) and np.array_equal(dp, p) and np.array_equal(dz, z) and np.array_equal(do, o)
+    ds2, dp2, dz2, do2 = dev.sample(32)
+    assert ds2.shape == (32, 10, 9, 9) and np.allclose(dp2.sum(1), 1, atol=1e-6)
+    dev.close()

@@ -66,6 +66,11 @@ SIGNATURES = {
     "tg_net_predict": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
     "tg_prof_enable": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "tg_prof_read": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]),
+    "tg_replay_create": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "tg_replay_destroy": (None, [_vp]),
+    "tg_replay_append": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int]),
+    "tg_replay_info": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_int)]),
+    "tg_replay_sample": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_int]),
     "tg_host_mt_seed": (None, [ctypes.POINTER(TgMt19937), ctypes.c_uint32]),
     "tg_host_mt_next32": (ctypes.c_uint32, [ctypes.POINTER(TgMt19937)]),
     "tg_host_mt_random_sample": (ctypes.c_double, [ctypes.POINTER(TgMt19937)]),

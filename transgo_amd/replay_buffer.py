@@ -63,3 +63,68 @@ class ReplayMemory_Random:
 
 def ReplayMemory(config):                                           # replay_buffer.py:7-10
     return ReplayMemory_Random(config)
+
+
+class DeviceReplayMemory:
+    """Replay store resident in HBM with the sampler on the GPU (libtransgo_hip tg_replay_*).
+
+    Holds each position once, un-augmented; `sample(batch_size)` returns what trainer.py:46-54 builds from the reference
+    buffer -- `state f32[B,C,S,S], pi f32[B,A], z f32[B], own f32[B,S*S]` -- for entries drawn exactly as
+    ReplayMemory_Random.sample draws them (replay_buffer.py:36-47), where entry e is (position e//8, symmetry e%8) in the
+    reference's append order.  `append_game` takes the GameRecord objects transgo_amd.self_play produces."""
+
+    def __init__(self, config, capacity_positions=None, device=0):
+        import ctypes
+        from . import _lib
+        self._ct, self._lib = ctypes, _lib
+        cfg = _lib.default_config()
+        cfg.board_size, cfg.encode_dim, cfg.n_games, cfg.device = config.board_size, config.encode_state_channels, 0, device
+        self.ctx = _lib.Context(cfg)
+        self.S, self.C = config.board_size, config.encode_state_channels
+        self.P, self.A = self.S ** 2, self.S ** 2 + 1
+        self.capacity = int(capacity_positions or max(1, int(config.buffer_size) // 8))
+        h = ctypes.c_void_p()
+        _lib.check(self.ctx.lib, self.ctx.h, self.ctx.lib.tg_replay_create(self.ctx.h, self.capacity, ctypes.byref(h)))
+        self.h = h
+        self.words = (self.C * self.P + 31) // 32
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.tg_replay_destroy(self.h); self.h = None
+            self.ctx.close()
+
+    def append_game(self, rec):
+        n = len(rec.players)
+        bits = np.zeros((n, self.words * 32), np.uint8)
+        bits[:, :self.C * self.P] = np.stack([np.asarray(o, np.uint8).reshape(-1) for o in rec.observations])
+        packed = np.packbits(bits, axis=1, bitorder="little").view(np.uint32)
+        counts = np.ascontiguousarray(np.stack(rec.visits), np.int32)
+        players = np.asarray(rec.players)
+        z = np.where(players == rec.winner, 1.0, -1.0).astype(np.float32)                       # self_play.py:931-934
+        terr = np.asarray(rec.territory, np.float32)
+        own = np.where((players == 1)[:, None], terr[None, :], -terr[None, :]).astype(np.int8)  # self_play.py:938-940
+        p = lambda a: a.ctypes.data_as(self._ct.c_void_p)
+        self._lib.check(self.ctx.lib, self.ctx.h, self.ctx.lib.tg_replay_append(self.h, p(np.ascontiguousarray(packed)), p(counts), p(z),
+                                                                                p(np.ascontiguousarray(own)), n))
+
+    def info(self):                                                  # replay_buffer.py:89-94, in units of reference entries
+        e, i, f = self._ct.c_longlong(), self._ct.c_longlong(), self._ct.c_int()
+        self.ctx.lib.tg_replay_info(self.h, self._ct.byref(e), self._ct.byref(i), self._ct.byref(f))
+        return {"capacity": self.capacity * 8, "index": i.value, "full": bool(f.value), "entries": e.value}
+
+    def sample_entries(self, entries):
+        entries = np.ascontiguousarray(entries, np.int64)
+        B = len(entries)
+        state = np.empty((B, self.C, self.S, self.S), np.float32); pi = np.empty((B, self.A), np.float32)
+        z = np.empty(B, np.float32); own = np.empty((B, self.P), np.float32)
+        p = lambda a: a.ctypes.data_as(self._ct.c_void_p)
+        self._lib.check(self.ctx.lib, self.ctx.h, self.ctx.lib.tg_replay_sample(self.h, p(entries), B, p(state), p(pi), p(z), p(own), 0))
+        return state, pi, z, own
+
+    def sample(self, batch_size):                                    # replay_buffer.py:36-47
+        buffer_len = self.info()["entries"]
+        if buffer_len < batch_size:
+            idx = np.random.choice(buffer_len, batch_size)
+        else:
+            idx = np.random.choice(buffer_len, batch_size, replace=False)
+        return self.sample_entries(idx)

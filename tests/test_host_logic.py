@@ -150,3 +150,32 @@ def test_vectorised_move_selection_equals_per_game_form():
         a1, p1 = choose_moves_reference(visits, steps, u, live, selfplay)
         a2, p2 = choose_moves_batch(visits, steps, u, live, selfplay)
         assert np.array_equal(a1, a2) and np.array_equal(p1, p2)
+
+
+def test_packed_replay_file_roundtrip(tmp_path):
+    """Packed on-disk format -> loader -> the reference tuple layout, identical to feeding the buffer directly."""
+    from transgo_amd.replay_buffer import load_packed, load_packed_into, save_packed
+    rng = np.random.RandomState(9)
+    recs = []
+    for g in range(3):
+        r = GameRecord(g)
+        for m in range(5 + g):
+            r.observations.append((rng.rand(10, 9, 9) < 0.3).astype(np.float32))
+            v = rng.randint(0, 50, 82).astype(np.int32); v[3] = 1; v[7] += 2
+            r.visits.append(v); c = np.where(v == 1, 0, v); r.pis.append(c / np.sum(c)); r.players.append(1 + m % 2)
+        r.winner = 1 + g % 2; r.territory = rng.randint(-1, 2, 81).astype(np.float32)
+        recs.append(r)
+    path = str(tmp_path / "replay.tgrp")
+    save_packed(path, recs, 9, 10)
+    assert os.path.getsize(path) < 3 * 8 * 450 + 400
+    back = load_packed(path)
+    assert len(back) == 3 and [len(r.players) for r in back] == [5, 6, 7]
+    cfg = Config(buffer_size=1024)
+    a, b = ReplayMemory_Random(cfg), ReplayMemory_Random(cfg)
+    for r in recs:
+        for t in game_targets(r.observations, r.pis, r.players, r.winner, r.territory, 9):
+            a.append(*t)
+    n = load_packed_into(path, b)
+    assert n == a.index == b.index == 8 * 18
+    for x, y in zip(a.data[:n], b.data[:n]):
+        assert all(np.array_equal(p, q) for p, q in zip(x, y))

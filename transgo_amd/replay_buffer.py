@@ -128,3 +128,45 @@ class DeviceReplayMemory:
         else:
             idx = np.random.choice(buffer_len, batch_size, replace=False)
         return self.sample_entries(idx)
+
+
+# ---- packed on-disk / wire format (replaces the pickled object arrays of replay_buffer.py:49-87) -----------
+# One file = a sequence of finished games in the exact, compact form that also travels between GPUs
+# (transgo_amd.distributed.pack_records): bit-packed planes (10*S*S bits), raw visit counts, side to move, and per game the
+# winner and territory.  ~0.43 KB per position instead of ~36 KB for its 8 pickled float tuples; pi / z / own and the 8
+# symmetries are regenerated bit-identically by the loader.
+_MAGIC = b"TGRP1\0"
+
+
+def save_packed(path, records, board_size, encode_dim):
+    from .distributed import pack_records
+    payload = pack_records(records, board_size, encode_dim)
+    with open(path, "wb") as f:
+        f.write(_MAGIC)
+        f.write(np.array([board_size, encode_dim, len(records)], np.int32).tobytes())
+        f.write(payload.tobytes())
+
+
+def load_packed(path):
+    """-> list of GameRecord (observations, visits, pis, players, winner, territory)."""
+    from .distributed import unpack_records
+    with open(path, "rb") as f:
+        if f.read(len(_MAGIC)) != _MAGIC:
+            raise ValueError("not a packed replay file")
+        S, C, n = np.frombuffer(f.read(12), np.int32)
+        recs = unpack_records(np.frombuffer(f.read(), np.uint8), int(S), int(C))
+    if len(recs) != n:
+        raise ValueError("truncated packed replay file")
+    return recs
+
+
+def load_packed_into(path, mem):
+    """Feed a packed file into any buffer with the reference's append(obs, pi, z, own) (replay_buffer.py:30-34), in the
+    reference's order.  Returns the number of tuples appended."""
+    from .self_play import game_targets
+    k = 0
+    for r in load_packed(path):
+        S = int(round(len(r.territory) ** 0.5))
+        for t in game_targets(r.observations, r.pis, r.players, r.winner, r.territory, S):
+            mem.append(*t); k += 1
+    return k

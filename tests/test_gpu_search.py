@@ -141,3 +141,19 @@ def test_policy_evaluate_runs_matches_and_reports():
         assert st.get_info("evaluate_score") == 200 and st.get_info("evaluate_weights") is w_new
     else:
         assert st.get_info("evaluate_score") == 100
+
+
+def test_arena_overflow_is_reported_not_fatal():
+    """A deliberately tiny tree arena: the engine must flag the games, return TG_ERR_ARENA and stay usable (no out-of-bounds
+    write, no endless search)."""
+    from transgo_amd._lib import TransgoError
+    from transgo_amd.engine import SelfPlayEngine
+    eng = SelfPlayEngine(4, num_simulation=64, evaluator=evaluators.flat, arena_slots=4 * 84 + 16)
+    eng.reset(np.arange(4))
+    with pytest.raises(TransgoError):
+        eng.search()
+    assert eng.stats()["errors"] >= 1
+    eng.close()
+    eng2 = SelfPlayEngine(2, num_simulation=8, evaluator=evaluators.flat)      # a fresh context still works
+    eng2.reset([1, 2]); eng2.search()
+    assert eng2.stats()["errors"] == 0

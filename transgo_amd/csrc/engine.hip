@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64) void k_collect(EngineDev d) {
     GameCtl* c = &d.ctl[g];
     const SearchCfg& sc = d.sc;
     if (lane == 0) c->n_paths = 0;
-    if (!c->searching) return;
+    if (!c->searching || c->error) return;           // a game in error (arena overflow) is parked, never retried
     NodeRec* arena = arena_of<S>(d.arena, g, c->cur, sc.arena_slots);
     if (arena[0].n >= c->n_target) { if (lane == 0) c->active = 0; return; }
     if (lane == 0) atomicAdd(&d.counters[CNT_ACTIVE], 1);
@@ -725,7 +725,10 @@ int tg_sp_absorb(tg_ctx* ctx) {
 int tg_sp_search(tg_ctx* ctx, int32_t* n_waves) {
     NEED_ENGINE(ctx);
     int waves = 0;
+    // every wave completes at least one simulation per active game, so num_simulation waves always suffice
+    const int max_waves = 2 * ctx->cfg.num_simulation + 1024;
     for (;;) {
+        if (waves > max_waves) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_search: no progress (wave limit exceeded)");
         int32_t active = 0, rows = 0;
         int rc = tg_sp_collect(ctx, &active, &rows);
         if (rc) return rc;

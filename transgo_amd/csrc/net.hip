@@ -79,11 +79,9 @@ __global__ __launch_bounds__(256) void k_obs_to_rows(const float* __restrict__ o
 
 // EPI 0: out = relu(acc + bias)      EPI 1: out = acc + bias + res      EPI 2: out = acc + bias
 // NTAP 9: 3x3 convolution with zero padding; NTAP 1: 1x1 convolution (the q/k/v projections of Self_Attention, model.py:294-296)
-#ifndef TG_CONV_MINW2
-#define TG_CONV_MINW2 1
-#endif
 template <int S, int CIN, int COUT, bool PRO, int EPI, int NTAP = 9, int NPT = 2>
-__global__ __launch_bounds__(256, (NPT > 2 ? 2 : TG_CONV_MINW2)) void k_conv3x3(const float* __restrict__ in, float* __restrict__ out,
+// NPT = 3 only pays with two waves per SIMD (<= 256 registers, a handful of spills): measured 132 vs 118 TFLOP/s at one
+__global__ __launch_bounds__(256, (NPT > 2 ? 2 : 1)) void k_conv3x3(const float* __restrict__ in, float* __restrict__ out,
                                                  const float* __restrict__ res, const float* __restrict__ Wt,
                                                  const float* __restrict__ bias, const float* __restrict__ ps,
                                                  const float* __restrict__ pt, int M) {
@@ -503,11 +501,7 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
     const int grid = (M + 127) / 128;                 // stem / head / 1x1 convs: 128 rows per workgroup
     // position tiles per wave in the F->F convs (workgroup = 64*NPT rows): 3 while the accumulators (F/16*NPT*4 registers)
     // still leave room for two waves per SIMD, else 2.  Measured at F=128: 128.0 -> 132.3 TFLOP/s.
-#ifdef TG_CONV_NPT_F
-    constexpr int NPT = TG_CONV_NPT_F;
-#else
     constexpr int NPT = F <= 128 ? 3 : 2;
-#endif
     const int grid_f = (M + 64 * NPT - 1) / (64 * NPT);
     // k_conv3x3_wp: independent waves of (16*WP_NPT rows) x (16*WP_CTW couts); 4 waves per workgroup
     constexpr int WP_CTW = (F / 16) < TG_WP_CTW ? (F / 16) : TG_WP_CTW;

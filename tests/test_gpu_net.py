@@ -105,3 +105,21 @@ def test_mainnetwork_default_width_vs_oracle():
     ep, ev, eo = np.abs(hp - p.numpy()).max(), np.abs(hv - v.numpy()).max(), np.abs(ho - o.numpy()).max()
     print(f"MainNetwork F=128: max abs err policy {ep:.2e} value {ev:.2e} own {eo:.2e}")
     assert ep < TOL and ev < TOL and eo < TOL
+
+
+def test_dma_conv_path_matches_torch(monkeypatch):
+    """The opt-in LDS-DMA conv path (TG_DMA_CONV=1: prologue-free chain, buffer_load..lds slabs, global_load_lds weight ring)."""
+    import torch
+    from oracle.net import seeded_tower
+    from transgo_amd.model import HipNetwork
+    monkeypatch.setenv("TG_DMA_CONV", "1")
+    torch.set_num_threads(4)
+    for S, NB, n in ((9, 3, 150), (19, 1, 5)):
+        net = seeded_tower(S, 10, 128, NB, seed=99)
+        x = _positions(S, n, 8)
+        with torch.no_grad():
+            p, v, o = net.main_prediction(torch.from_numpy(x))
+        h = HipNetwork(S, 10, 128, NB, rows_cap=64)
+        h.set_weights(net.get_weights())
+        hp, hv, ho = h.main_prediction(x)
+        assert np.abs(hp - p.numpy()).max() < TOL and np.abs(hv - v.numpy()).max() < TOL and np.abs(ho - o.numpy()).max() < TOL

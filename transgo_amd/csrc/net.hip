@@ -15,6 +15,7 @@
 // of materialising padded boards.  BatchNorm is folded on the host (transgo_amd/model.py): BN that follows a conv goes
 // into its weights/bias, BN that precedes one (pre-activation) is applied with ReLU while the tile is staged into LDS.
 #include <cmath>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -36,6 +37,8 @@ struct Net {
     ConvW stem; std::vector<BlockW> blocks; std::vector<Layer> layers; const float* s_end = nullptr; const float* t_end = nullptr;
     bool pol_att = false; AttW patt; ConvW head_a; std::string arch;
     float* bufQ = nullptr; float* hca = nullptr;   // q|k|v projections [rows][P][1.5F]; policy head conv output
+    float* bufAct = nullptr;                       // pre-activated input of the next conv (DMA path)
+    bool dma = false;                              // attention-free F=128 tower: k_conv3x3_dma path
     ConvW head; const float* w_vo = nullptr; const float* b_vo = nullptr; const float* w_v = nullptr; const float* b_v = nullptr;
     const float* w_o = nullptr; const float* b_o = nullptr; const float* w_a = nullptr; const float* b_a = nullptr;
     float* x0 = nullptr;   // [rows][P][16] input planes, channel-minor
@@ -53,14 +56,14 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-#ifndef TG_WP_CTW
-#define TG_WP_CTW 4          // cout tiles (of 16) per wave in k_conv3x3_wp
+#ifndef TG_DMA_NPT
+#define TG_DMA_NPT 4
 #endif
-#ifndef TG_WP_ACC
-#define TG_WP_ACC 32         // accumulator tiles per wave (x4 registers)
+#ifndef TG_WP_CTW
+#define TG_WP_CTW 8          // cout tiles (of 16) per fragment group of the fragment-ordered weight copy (k_conv3x3_dma: all 8 of F=128)
 #endif
 #ifndef TG_WP_CC
-#define TG_WP_CC 16          // input channels per activation slice of k_conv3x3_wp
+#define TG_WP_CC 16          // input channels per activation slice of k_conv3x3_dma
 #endif
 
 
@@ -84,7 +87,8 @@ template <int S, int CIN, int COUT, bool PRO, int EPI, int NTAP = 9, int NPT = 2
 __global__ __launch_bounds__(256, (NPT > 2 ? 2 : 1)) void k_conv3x3(const float* __restrict__ in, float* __restrict__ out,
                                                  const float* __restrict__ res, const float* __restrict__ Wt,
                                                  const float* __restrict__ bias, const float* __restrict__ ps,
-                                                 const float* __restrict__ pt, int M) {
+                                                 const float* __restrict__ pt, int M, float* __restrict__ out2 = nullptr,
+                                                 const float* __restrict__ s2 = nullptr, const float* __restrict__ t2 = nullptr) {
     constexpr int P = S * S, HALO = NTAP == 9 ? S + 1 : 0;
     constexpr int TM = 64 * NPT;                    // output rows per workgroup: 4 waves x NPT position tiles x 16
     constexpr int CC = CIN < 32 ? CIN : 32;         // input channels staged per pass
@@ -224,45 +228,76 @@ __global__ __launch_bounds__(256, (NPT > 2 ? 2 : 1)) void k_conv3x3(const float*
                 v = v + *reinterpret_cast<const f32x4*>(res + (size_t)m * COUT + co);
             }
             *reinterpret_cast<f32x4*>(out + (size_t)m * COUT + co) = v;
+            if (out2) {                               // the next layer's pre-activated input: relu(bn_next(v))
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(s2 + co), sh = *reinterpret_cast<const f32x4*>(t2 + co);
+                f32x4 u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float w = v[e] * sc[e] + sh[e]; u[e] = w > 0.f ? w : 0.f; }
+                *reinterpret_cast<f32x4*>(out2 + (size_t)m * COUT + co) = u;
+            }
         }
     }
 }
 
 
-// ---- EXPERIMENTAL (build with -DTG_CONV_WP; measured 117 TFLOP/s vs 128 for k_conv3x3) ----
-// ---- wave-private 3x3 conv (the F->F convs of the tower: 99 % of the network's FLOPs) ---------------------------------------
-// Every wave is an independent worker: 64 consecutive rows x all COUT channels (4 position tiles x COUT/16 cout tiles of
-// v_mfma_f32_16x16x4_f32, accumulators in registers), NO workgroup barrier anywhere.  Activations: the wave's own 64+2*HALO
-// rows, 32 input channels at a time, in a wave-private LDS slab (+ one all-zero row that out-of-board taps are
-// redirected to, so no masking happens in the MFMA stream).  Weights: never staged -- each A fragment is one fully
-// coalesced 1-KB wave load from a fragment-ordered copy of the weights ([slice][tap][sub][cout tile][lane][4], built at load
-// time) that streams linearly through L2/L1, four fragments (= 64 MFMAs) ahead of use.
-template <int S, int F, bool PRO, int EPI, int NPT, int CTW>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_wp(const float* __restrict__ in, float* __restrict__ out,
-                                                       const float* __restrict__ res, const float* __restrict__ Wf,
-                                                       const float* __restrict__ bias, const float* __restrict__ ps,
-                                                       const float* __restrict__ pt, int M) {
-    constexpr int P = S * S, HALO = S + 1, WT = 16 * NPT;
-    constexpr int CC = TG_WP_CC, RS = CC + 4, C4 = CC / 4, NSUB = CC / 16;
-    constexpr int NROW = WT + 2 * HALO;              // rows staged per wave
-    constexpr int ZROW = NROW;                       // index of the all-zero row
-    constexpr int CT = CTW;                          // cout tiles held by this wave
-    constexpr int NG = (F / 16) / CTW;               // cout groups: NG waves share one row block
-    constexpr int XL = (NROW * C4 + 63) / 64;        // activation float4 per lane per slice
-    constexpr int NFRAG = (F / CC) * 9 * NSUB * CT;  // A fragments per tile
-    constexpr int DEPTH = ((CC / 16) * CTW) % 4 == 0 ? 4 : 2;   // fragments in flight
-    static_assert((NSUB * CT) % DEPTH == 0, "prefetch ring must divide the fragments of one tap");
-    __shared__ float lds[4][(NROW + 1) * RS];
+
+// ---- ALTERNATIVE PATH (TG_DMA_CONV=1 in the environment; 129 TFLOP/s vs 132 for k_conv3x3; parity-tested) ----------------
+// ---- LDS-DMA 3x3 conv for the F->F convs of an attention-free tower --------------------------------------------------------
+// Every wave is an independent worker (no workgroup barrier anywhere): 16*NPT consecutive rows x all F output channels,
+// NPT x F/16 accumulator tiles of v_mfma_f32_16x16x4_f32.  Nothing is staged through registers:
+//   * activations (already activated by the producer's epilogue): the wave's 16*NPT + 2*(S+1) rows, 16 channels at a time, land in
+//     one of two wave-private LDS slabs by `buffer_load ... lds`; rows outside the batch come back as zeros from the buffer
+//     bounds check, taps that leave the board read a dedicated zero row;
+//   * weights: a fragment-ordered copy ([slice][tap][cout tile][lane][4], built at load time) streams through an 8-deep
+//     wave-private LDS ring by `global_load_lds` (1 KB fully coalesced per fragment), 8 fragments = 128 MFMAs ahead of use;
+//   * every wait is a counted `s_waitcnt vmcnt(N)`: DMAs retire in issue order, the ring keeps 7 younger fragments in
+//     flight, plus the 6 slab pieces while the next slice is arriving (last tap of a slice).
+typedef __attribute__((address_space(3))) void tg_lds_void;
+#define TG_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+template <int S, int F, int EPI, int NPT>
+__global__ __launch_bounds__(128, 2) void k_conv3x3_dma(const float* __restrict__ in, float* __restrict__ out,
+                                                        const float* __restrict__ res, const float* __restrict__ Wf,
+                                                        const float* __restrict__ bias, float* __restrict__ out2,
+                                                        const float* __restrict__ s2, const float* __restrict__ t2, int M) {
+    constexpr int P = S * S, HALO = S + 1, WT = 16 * NPT, CT = F / 16;
+    constexpr int CC = 16, NSL = F / CC;
+    constexpr int NROW = WT + 2 * HALO;               // rows per slab
+    constexpr int NX = (NROW + 15) / 16;              // DMA pieces per slab (16 rows x 64 B each)
+    constexpr int NR = 8;                             // ring depth = fragments per tap
+    static_assert(CT == NR, "one tap's fragments fill the ring exactly (F = 128)");
+    constexpr int NFRAG = NSL * 9 * CT;
+    constexpr int SLAB = NROW * CC;                   // floats
+    __shared__ __attribute__((aligned(16))) float lds[2][2 * SLAB + NR * 256 + 16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int j = lane & 15, kq = lane >> 4;
-    const int wid = blockIdx.x * 4 + wave;
-    const int cg = wid % NG;                         // which CTW*16 couts
-    const int m0 = (wid / NG) * WT;
-    if (m0 >= M) return;                             // whole wave out of range (no barriers in this kernel)
-    float* xs = lds[wave];
+    const int m0 = (blockIdx.x * 2 + wave) * WT;
+    if (m0 >= M) return;
+    float* slab = lds[wave];                          // [2][NROW][16]
+    float* ring = slab + 2 * SLAB;                    // [NR][64 lanes][4]
+    float* zrow = ring + NR * 256;                    // [16] zeros
+    if (lane < 4) *reinterpret_cast<f32x4*>(zrow + lane * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int vrow[NPT];                                   // LDS row of each position tile's lane row, before the tap offset
-    unsigned vmask[NPT];
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, M * F * 4, 0x00020000);
+    // piece q of slice sl: lane -> row 16q + lane/4, 16-byte chunk lane%4 (rows past NROW are skipped)
+    const int xrow = lane >> 2, xch = lane & 3;
+    auto dma_x = [&](int sl, int buf) {
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            const int r = q * 16 + xrow;
+            if (r < NROW) {
+                const int voff = ((m0 - HALO + r) * F + sl * CC + xch * 4) * 4;        // negative / past the end: reads back 0
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (tg_lds_void*)(slab + buf * SLAB + q * 256), 16, voff, 0, 0, 0);
+            }
+        }
+    };
+    const float* wf = Wf + lane * 4;
+    auto dma_w = [&](int f, int slot) {
+        f = f < NFRAG ? f : NFRAG - 1;
+        __builtin_amdgcn_global_load_lds(wf + (size_t)f * 256, (tg_lds_void*)(ring + slot * 256), 16, 0, 0);
+    };
+
+    int vrow[NPT]; unsigned vmask[NPT];
 #pragma unroll
     for (int t = 0; t < NPT; ++t) {
         const int m = m0 + t * 16 + j;
@@ -275,100 +310,63 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wp(const float* __restrict__
                 if (yy >= 0 && yy < S && xx >= 0 && xx < S) mk |= 1u << tap;
             }
         }
-        vmask[t] = mk;
-        vrow[t] = t * 16 + j + HALO;
+        vmask[t] = mk; vrow[t] = (t * 16 + j + HALO) * CC;
     }
-    for (int i = lane; i < RS; i += 64) xs[ZROW * RS + i] = 0.f;
-
     f32x4 acc[CT][NPT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int t = 0; t < NPT; ++t) acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    f32x4 xreg[XL];
-    auto load_x = [&](int cc) {
+    dma_x(0, 0);
 #pragma unroll
-        for (int i = 0; i < XL; ++i) {
-            const int idx = lane + i * 64;
-            xreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (idx < NROW * C4) {
-                const int r = idx / C4, c4 = idx % C4;
-                const int m = m0 - HALO + r;
-                if (m >= 0 && m < M) xreg[i] = *reinterpret_cast<const f32x4*>(in + (size_t)m * F + cc + c4 * 4);
-            }
-        }
-    };
-    auto store_x = [&](int cc) {
-#pragma unroll
-        for (int i = 0; i < XL; ++i) {
-            const int idx = lane + i * 64;
-            if (idx < NROW * C4) {
-                const int r = idx / C4, c4 = idx % C4;
-                f32x4 v = xreg[i];
-                if (PRO) {
-                    const int m = m0 - HALO + r;
-                    if (m >= 0 && m < M) {
-                        const f32x4 sc = *reinterpret_cast<const f32x4*>(ps + cc + c4 * 4);
-                        const f32x4 sh = *reinterpret_cast<const f32x4*>(pt + cc + c4 * 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { float u = v[e] * sc[e] + sh[e]; v[e] = u > 0.f ? u : 0.f; }
-                    }
-                }
-                *reinterpret_cast<f32x4*>(&xs[r * RS + c4 * 4]) = v;
-            }
-        }
-    };
+    for (int d = 0; d < NR; ++d) dma_w(d, d);
+    TG_VMCNT(NR - 1);                                 // slab 0 and fragment 0 have landed (NR-1 younger ring DMAs in flight)
+    f32x4 a_cur = *reinterpret_cast<const f32x4*>(ring + lane * 4);
 
-    const f32x4* wf = reinterpret_cast<const f32x4*>(Wf) + (size_t)cg * NFRAG * 64 + lane;   // fragment f of this cout group at wf[f * 64]
-    f32x4 aq[DEPTH];
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) aq[d] = wf[(size_t)d * 64];
-    int fbase = 0;                                                   // index of the fragment held in aq[0]
-
-    load_x(0);
-    store_x(0);
-    // wave-private LDS needs no fence: one wave's DS instructions execute in issue order, and the compiler keeps the
-    // order of possibly-aliasing accesses to the same array
-
-    for (int cc = 0; cc < F; cc += CC) {
+    // One fragment ahead: while the 16 MFMAs of fragment f run, fragment f+1 is already being read out of the ring, and
+    // slot f is refilled (fragment f+NR) as soon as they have issued.  Counted waits (DMAs retire in issue order):
+    // fragment f+1 is complete once at most NR-2 younger ring DMAs remain -- plus the NX slab pieces during the last tap of a
+    // slice for fragments that were issued before them.
+    int fbase = 0;
+    for (int sl = 0; sl < NSL; ++sl) {
+        const float* xs = slab + (sl & 1) * SLAB;
+        const bool more = sl + 1 < NSL;
         for (int tap = 0; tap < 9; ++tap) {
-            if (tap == 8 && cc + CC < F) load_x(cc + CC);            // next slice lands while this tap computes
-            const int toff = (tap / 3 - 1) * S + (tap % 3 - 1);
-            int brow[NPT];
+            const int toff = ((tap / 3 - 1) * S + (tap % 3 - 1)) * CC;
+            const bool prefetch_x = more && tap == 8;
+            if (prefetch_x) dma_x(sl + 1, (sl + 1) & 1);
+            f32x4 b[NPT];
 #pragma unroll
-            for (int t = 0; t < NPT; ++t) brow[t] = ((vmask[t] >> tap) & 1) ? (vrow[t] + toff) : ZROW;
-#pragma unroll
-            for (int sub = 0; sub < NSUB; ++sub) {
-                f32x4 b[NPT];
-#pragma unroll
-                for (int t = 0; t < NPT; ++t) b[t] = *reinterpret_cast<const f32x4*>(&xs[brow[t] * RS + sub * 16 + kq * 4]);
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const int q = (sub * CT + ct) % DEPTH;
-                    const f32x4 a = aq[q];
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                        for (int t = 0; t < NPT; ++t)
-                            acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[t][s4], acc[ct][t], 0, 0, 0);
-                    int fn = fbase + sub * CT + ct + DEPTH;
-                    fn = fn < NFRAG ? fn : NFRAG - 1;                // past the end: harmless re-read
-                    aq[q] = wf[(size_t)fn * 64];
-                    __builtin_amdgcn_sched_barrier(0);               // keep the load HERE: hipcc otherwise sinks it to its use
-                }
+            for (int t = 0; t < NPT; ++t) {
+                const float* src = ((vmask[t] >> tap) & 1) ? xs + vrow[t] + toff + kq * 4 : zrow + kq * 4;
+                b[t] = *reinterpret_cast<const f32x4*>(src);
             }
-            fbase += NSUB * CT;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                if (prefetch_x && ct < CT - 1) TG_VMCNT(NR - 2 + NX); else TG_VMCNT(NR - 2);
+                const f32x4 a_next = *reinterpret_cast<const f32x4*>(ring + ((ct + 1) % NR) * 256 + lane * 4);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int t = 0; t < NPT; ++t)
+                        acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s4], b[t][s4], acc[ct][t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                dma_w(fbase + ct + NR, ct);          // refill the slot whose fragment (a_cur) left the ring one step ago
+                __builtin_amdgcn_sched_barrier(0);
+                a_cur = a_next;
+            }
+            fbase += NR;
         }
-        if (cc + CC < F) store_x(cc + CC);
     }
+    TG_VMCNT(0);                                      // no DMA may outlive the wave's LDS
 #pragma unroll
     for (int t = 0; t < NPT; ++t) {
         const int m = m0 + t * 16 + j;
         if (m >= M) continue;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            const int co = (cg * CTW + ct) * 16 + kq * 4;
+            const int co = ct * 16 + kq * 4;
             const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + co);
             f32x4 v = acc[ct][t] + bv;
             if (EPI == 0) {
@@ -378,10 +376,16 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wp(const float* __restrict__
                 v = v + *reinterpret_cast<const f32x4*>(res + (size_t)m * F + co);
             }
             *reinterpret_cast<f32x4*>(out + (size_t)m * F + co) = v;
+            if (out2) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(s2 + co), sh = *reinterpret_cast<const f32x4*>(t2 + co);
+                f32x4 u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float w = v[e] * sc[e] + sh[e]; u[e] = w > 0.f ? w : 0.f; }
+                *reinterpret_cast<f32x4*>(out2 + (size_t)m * F + co) = u;
+            }
         }
     }
 }
-
 
 // Self_Attention core (model.py:301-315) for one board per workgroup, after the fused q/k/v 1x1 projection:
 //   energy[i][j] = q_i . k_j ; attention = softmax_j(energy) ; out[:, j] = sum_i v[:, i] * attention[i][j]   (note: summed over
@@ -503,19 +507,42 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
     // still leave room for two waves per SIMD, else 2.  Measured at F=128: 128.0 -> 132.3 TFLOP/s.
     constexpr int NPT = F <= 128 ? 3 : 2;
     const int grid_f = (M + 64 * NPT - 1) / (64 * NPT);
-    // k_conv3x3_wp: independent waves of (16*WP_NPT rows) x (16*WP_CTW couts); 4 waves per workgroup
-    constexpr int WP_CTW = (F / 16) < TG_WP_CTW ? (F / 16) : TG_WP_CTW;
-    constexpr int WP_NPT = TG_WP_ACC / WP_CTW;
-    constexpr int WP_NG = (F / 16) / WP_CTW;
-    const int n_waves = ((M + 16 * WP_NPT - 1) / (16 * WP_NPT)) * WP_NG;
-    const int grid_w = (n_waves + 3) / 4;
-    (void)grid_w;
     const double conv_flops = 2.0 * 9.0 * (double)F * (double)F * (double)M;
     int g0 = (int)(((size_t)M * 16 + 255) / 256); if (g0 > 65535) g0 = 65535;
     hipLaunchKernelGGL((k_obs_to_rows<S>), dim3(g0), dim3(256), 0, st, obs, n->x0, rows, n->C);
     hipLaunchKernelGGL((k_conv3x3<S, 16, F, false, 0>), dim3(grid), dim3(256), 0, st, (const float*)n->x0, n->bufA,
                        (const float*)nullptr, n->stem.w, n->stem.b, (const float*)nullptr, (const float*)nullptr, M);
     float* x = n->bufA; float* y = n->bufB;
+    if constexpr (F == 128) {
+        if (n->dma && (long long)M * F * 4 < (1ll << 31)) {
+            // prologue-free chain: every producer also writes relu(bn_next(.)) for its consumer
+            constexpr int DNPT = TG_DMA_NPT;
+            const int grid_d = ((M + 16 * DNPT - 1) / (16 * DNPT) + 1) / 2;
+            const size_t nb = n->blocks.size();
+            const float* s0 = nb ? n->blocks[0].s1 : n->s_end; const float* t0 = nb ? n->blocks[0].t1 : n->t_end;
+            hipLaunchKernelGGL((k_conv3x3<S, 16, F, false, 0>), dim3(grid), dim3(256), 0, st, (const float*)n->x0, x,
+                               (const float*)nullptr, n->stem.w, n->stem.b, (const float*)nullptr, (const float*)nullptr, M,
+                               n->bufAct, s0, t0);
+            for (size_t i = 0; i < nb; ++i) {
+                const BlockW& b = n->blocks[i];
+                const float* sn = i + 1 < nb ? n->blocks[i + 1].s1 : n->s_end;
+                const float* tn = i + 1 < nb ? n->blocks[i + 1].t1 : n->t_end;
+                { ProfScope ps(n, st, conv_flops);
+                  hipLaunchKernelGGL((k_conv3x3_dma<S, F, 0, DNPT>), dim3(grid_d), dim3(128), 0, st, (const float*)n->bufAct, n->bufH,
+                                     (const float*)nullptr, b.f1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M); }
+                { ProfScope ps(n, st, conv_flops);
+                  hipLaunchKernelGGL((k_conv3x3_dma<S, F, 1, DNPT>), dim3(grid_d), dim3(128), 0, st, (const float*)n->bufH, y,
+                                     (const float*)x, b.f2, b.c2.b, n->bufAct, sn, tn, M); }
+                float* t = x; x = y; y = t;
+            }
+            hipLaunchKernelGGL((k_conv3x3<S, F, 16, false, 0>), dim3(grid), dim3(256), 0, st, (const float*)n->bufAct, n->hc,
+                               (const float*)nullptr, n->head.w, n->head.b, (const float*)nullptr, (const float*)nullptr, M);
+            hipLaunchKernelGGL((k_heads<S>), dim3(rows), dim3(256), 0, st, (const float*)n->hc, (const float*)n->hc, n->w_vo, n->b_vo,
+                               n->w_v, n->b_v, n->w_o, n->b_o, n->w_a, n->b_a, policy, value, own);
+            TG_HIP(ctx, hipGetLastError());
+            return TG_OK;
+        }
+    }
     // attention block: fused q|k|v 1x1 projection on the matrix cores, then the per-board core (model.py:301-315)
     constexpr int W = F / 4 + F / 4 + F;
     constexpr size_t att_lds = sizeof(float) * ((size_t)P * W + (size_t)P * (P + 1));
@@ -539,22 +566,12 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
         }
         const BlockW& b = n->blocks[L.ridx];
         { ProfScope ps(n, st, conv_flops);
-#ifdef TG_CONV_WP
-          hipLaunchKernelGGL((k_conv3x3_wp<S, F, true, 0, WP_NPT, WP_CTW>), dim3(grid_w), dim3(256), 0, st, (const float*)x, n->bufH,
-                             (const float*)nullptr, b.f1, b.c1.b, b.s1, b.t1, M);
-#else
           hipLaunchKernelGGL((k_conv3x3<S, F, F, true, 0, 9, NPT>), dim3(grid_f), dim3(256), 0, st, (const float*)x, n->bufH,
                              (const float*)nullptr, b.c1.w, b.c1.b, b.s1, b.t1, M);
-#endif
         }
         { ProfScope ps(n, st, conv_flops);
-#ifdef TG_CONV_WP
-          hipLaunchKernelGGL((k_conv3x3_wp<S, F, false, 1, WP_NPT, WP_CTW>), dim3(grid_w), dim3(256), 0, st, (const float*)n->bufH, y,
-                             (const float*)x, b.f2, b.c2.b, (const float*)nullptr, (const float*)nullptr, M);
-#else
           hipLaunchKernelGGL((k_conv3x3<S, F, F, false, 1, 9, NPT>), dim3(grid_f), dim3(256), 0, st, (const float*)n->bufH, y,
                              (const float*)x, b.c2.w, b.c2.b, (const float*)nullptr, (const float*)nullptr, M);
-#endif
         }
         float* t = x; x = y; y = t;
     }
@@ -666,6 +683,8 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
         TG_HIP(ctx, hipMalloc((void**)&n->frag, sizeof(float) * (size_t)(NB > 0 ? 2 * NB : 1) * 9 * F * F));
         if (any_att) TG_HIP(ctx, hipMalloc((void**)&n->bufQ, sizeof(float) * (size_t)rows_cap * P * Wq));
         if (pol) TG_HIP(ctx, hipMalloc((void**)&n->hca, sizeof(float) * (size_t)rows_cap * P * 16));
+        n->dma = !any_att && F == 128 && getenv("TG_DMA_CONV") != nullptr;   // opt-in alternative (129 vs 132 TFLOP/s)
+        if (n->dma) TG_HIP(ctx, hipMalloc((void**)&n->bufAct, act));
         const float* p = n->blob;
         auto take = [&](size_t k) { const float* q = p; p += k; return q; };
         auto take_att = [&](AttW& a) { a.qkv.w = take(Wq * F); a.qkv.b = take(Wq); a.gamma = take(1); a.s = take(F); a.t = take(F); };
@@ -703,7 +722,7 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
     }
     // weight refresh (trainer.py:76-79 -> self_play.py:913) is just this copy
     TG_HIP(ctx, hipMemcpyAsync(n->blob, blob, sizeof(float) * n_floats, hipMemcpyHostToDevice, ctx->stream));
-    // fragment-ordered copies of the F->F conv weights for k_conv3x3_wp:
+    // fragment-ordered copies of the F->F conv weights for k_conv3x3_dma:
     //   frag f = group*NFRAG + ((slice*9 + tap)*NSUB + sub)*CTW + ct ; element [f][lane][e] = W[tap][ct*16 + (lane&15)][slice*CC + sub*16 + (lane>>4)*4 + e]
     {
         const size_t per = 9 * (size_t)F * F;
@@ -741,7 +760,7 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
 void tg_net_destroy(tg_ctx* ctx) {
     if (!ctx || !ctx->eng || !ctx->eng->net) return;
     Net* n = ctx->eng->net;
-    void* ptrs[] = {n->blob, n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->frag, n->bufQ, n->hca};
+    void* ptrs[] = {n->blob, n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->frag, n->bufQ, n->hca, n->bufAct};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t ev : n->ev) (void)hipEventDestroy(ev);
     delete n;

@@ -107,12 +107,14 @@ def test_mainnetwork_default_width_vs_oracle():
     assert ep < TOL and ev < TOL and eo < TOL
 
 
-def test_dma_conv_path_matches_torch(monkeypatch):
-    """The opt-in LDS-DMA conv path (TG_DMA_CONV=1: prologue-free chain, buffer_load..lds slabs, global_load_lds weight ring)."""
+@pytest.mark.parametrize("variant", ["0", "1", "2"])
+def test_dma_conv_path_matches_torch(monkeypatch, variant):
+    """All three F->F conv paths of the F=128 tower: TG_DMA_CONV=2 (default) shared swizzled LDS-DMA tile, one barrier per
+    stage, 3 workgroups per CU (k_conv3x3_sd); =1 wave-private LDS-DMA ring (k_conv3x3_dma); =0 register-staged (k_conv3x3)."""
     import torch
     from oracle.net import seeded_tower
     from transgo_amd.model import HipNetwork
-    monkeypatch.setenv("TG_DMA_CONV", "1")
+    monkeypatch.setenv("TG_DMA_CONV", variant)
     torch.set_num_threads(4)
     for S, NB, n in ((9, 3, 150), (19, 1, 5)):
         net = seeded_tower(S, 10, 128, NB, seed=99)

@@ -26,19 +26,20 @@ using namespace tg;
 namespace tg {
 
 struct ConvW { const float* w; const float* b; };
-struct BlockW { const float* s1; const float* t1; ConvW c1; ConvW c2; const float* f1; const float* f2; };   // f1/f2: fragment-ordered copies
+struct BlockW { const float* s1; const float* t1; ConvW c1; ConvW c2; const float* f1; const float* f2; const float* g1; const float* g2; };   // f1/f2: fragment-ordered copies
 struct AttW { ConvW qkv; const float* gamma; const float* s; const float* t; };      // Self_Attention, model.py:288-315
 struct Layer { int kind; int ridx; AttW a; };                                         // kind 0: residual block blocks[ridx]; 1: attention
 
 struct Net {
     int F = 0, NB = 0, C = 0, S = 0, P = 0, A = 0;
     float* blob = nullptr; size_t blob_floats = 0;
-    float* frag = nullptr;   // [2*NB][F/32][9][2][F/16][64][4] fragment-ordered F->F conv weights
+    float* frag = nullptr;   // [2*NB][...] fragment-ordered F->F conv weights (k_conv3x3_dma)
+    float* wstage = nullptr; // [2*NB][F/16*9][F][16] stage-ordered F->F conv weights (k_conv3x3_sd)
     ConvW stem; std::vector<BlockW> blocks; std::vector<Layer> layers; const float* s_end = nullptr; const float* t_end = nullptr;
     bool pol_att = false; AttW patt; ConvW head_a; std::string arch;
     float* bufQ = nullptr; float* hca = nullptr;   // q|k|v projections [rows][P][1.5F]; policy head conv output
     float* bufAct = nullptr;                       // pre-activated input of the next conv (DMA path)
-    bool dma = false;                              // attention-free F=128 tower: k_conv3x3_dma path
+    int dma = 0;                                   // attention-free F=128 tower: 2 = k_conv3x3_sd (default), 1 = k_conv3x3_dma, 0 = k_conv3x3
     ConvW head; const float* w_vo = nullptr; const float* b_vo = nullptr; const float* w_v = nullptr; const float* b_v = nullptr;
     const float* w_o = nullptr; const float* b_o = nullptr; const float* w_a = nullptr; const float* b_a = nullptr;
     float* x0 = nullptr;   // [rows][P][16] input planes, channel-minor
@@ -55,6 +56,7 @@ struct Net {
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ int tid0() { return (int)threadIdx.x; }
 
 #ifndef TG_DMA_NPT
 #define TG_DMA_NPT 4
@@ -80,6 +82,59 @@ __global__ __launch_bounds__(256) void k_obs_to_rows(const float* __restrict__ o
     }
 }
 
+
+// Conv epilogue shared by the conv kernels.  acc[ct][t] holds couts ct*16 + kq*4 .. +3 of row mrow[t].
+// Loads and stores retire through ONE in-order counter (vmcnt), so a load issued after stores waits for all of them: per-cout
+// parameters therefore come from LDS (par = bias | s2 | t2, COUT floats each), and the residual is fetched one 4-tile chunk
+// ahead of the stores of the previous chunk, which turns ~CT*NPT serialized memory round trips into counted, overlapped ones.
+// EPI 0: relu(acc + bias)   EPI 1: acc + bias + res   EPI 2: acc + bias;   out2 (optional) = relu(v * s2 + t2).
+template <int COUT, int CT, int NPT, int EPI>
+__device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[CT][NPT], const int (&mrow)[NPT], int M, int co_base, int kq,
+                                              float* __restrict__ out, const float* __restrict__ res, float* __restrict__ out2,
+                                              const float* par) {
+    constexpr int CH = CT % 4 == 0 ? 4 : CT % 3 == 0 ? 3 : CT % 2 == 0 ? 2 : 1;   // cout tiles per chunk
+    constexpr int NCH = (CT / CH) * NPT;
+    static_assert(CT % CH == 0, "chunking");
+    f32x4 r[2][CH];
+    auto load_res = [&](int c, f32x4* dst) {
+        const int t = c / (CT / CH), h = c % (CT / CH);
+        if (mrow[t] < M) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+                dst[i] = *reinterpret_cast<const f32x4*>(res + (size_t)mrow[t] * COUT + co_base + (h * CH + i) * 16 + kq * 4);
+        }
+    };
+    if (EPI == 1) load_res(0, r[0]);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int t = c / (CT / CH), h = c % (CT / CH);
+        if (EPI == 1 && c + 1 < NCH) load_res(c + 1, r[(c + 1) & 1]);
+        if (mrow[t] < M) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int ct = h * CH + i;
+                const int col = ct * 16 + kq * 4;      // column within this kernel's cout range
+                f32x4 v = acc[ct][t] + *reinterpret_cast<const f32x4*>(par + col);
+                if (EPI == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                } else if (EPI == 1) {
+                    v = v + r[c & 1][i];
+                }
+                *reinterpret_cast<f32x4*>(out + (size_t)mrow[t] * COUT + co_base + col) = v;
+                if (out2) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(par + COUT + col);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(par + 2 * COUT + col);
+                    f32x4 u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { float w = v[e] * sc[e] + sh[e]; u[e] = w > 0.f ? w : 0.f; }
+                    *reinterpret_cast<f32x4*>(out2 + (size_t)mrow[t] * COUT + co_base + col) = u;
+                }
+            }
+        }
+    }
+}
+
 // EPI 0: out = relu(acc + bias)      EPI 1: out = acc + bias + res      EPI 2: out = acc + bias
 // NTAP 9: 3x3 convolution with zero padding; NTAP 1: 1x1 convolution (the q/k/v projections of Self_Attention, model.py:294-296)
 template <int S, int CIN, int COUT, bool PRO, int EPI, int NTAP = 9, int NPT = 2>
@@ -97,6 +152,8 @@ __global__ __launch_bounds__(256, (NPT > 2 ? 2 : 1)) void k_conv3x3(const float*
     constexpr int CT = COUT / 16;                   // cout tiles, all held by every wave
     constexpr int C4 = CC / 4;
     __shared__ float xs[NROW * RS];
+    __shared__ __attribute__((aligned(16))) float par[3 * COUT];            // bias | s2 | t2 for the epilogue
+    for (int i = tid0(); i < COUT; i += 256) { par[i] = bias[i]; par[COUT + i] = out2 ? s2[i] : 0.f; par[2 * COUT + i] = out2 ? t2[i] : 0.f; }
     __shared__ float ws[COUT * RS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int j = lane & 15, kq = lane >> 4;
@@ -212,36 +269,13 @@ __global__ __launch_bounds__(256, (NPT > 2 ? 2 : 1)) void k_conv3x3(const float*
         }
     }
     // D tile: row (lane>>4)*4 + r = cout, column lane&15 = position
+    int mrow[NPT];
 #pragma unroll
-    for (int t = 0; t < NPT; ++t) {
-        const int m = m0 + (wave * NPT + t) * 16 + j;
-        if (m >= M) continue;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            const int co = ct * 16 + kq * 4;
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + co);
-            f32x4 v = acc[ct][t] + bv;
-            if (EPI == 0) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-            } else if (EPI == 1) {
-                v = v + *reinterpret_cast<const f32x4*>(res + (size_t)m * COUT + co);
-            }
-            *reinterpret_cast<f32x4*>(out + (size_t)m * COUT + co) = v;
-            if (out2) {                               // the next layer's pre-activated input: relu(bn_next(v))
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(s2 + co), sh = *reinterpret_cast<const f32x4*>(t2 + co);
-                f32x4 u;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { float w = v[e] * sc[e] + sh[e]; u[e] = w > 0.f ? w : 0.f; }
-                *reinterpret_cast<f32x4*>(out2 + (size_t)m * COUT + co) = u;
-            }
-        }
-    }
+    for (int t = 0; t < NPT; ++t) mrow[t] = m0 + (wave * NPT + t) * 16 + j;
+    conv_epilogue<COUT, CT, NPT, EPI>(acc, mrow, M, 0, kq, out, res, out2, par);
 }
 
-
-
-// ---- ALTERNATIVE PATH (TG_DMA_CONV=1 in the environment; 129 TFLOP/s vs 132 for k_conv3x3; parity-tested) ----------------
+// ---- ALTERNATIVE PATH (TG_DMA_CONV=1 in the environment; 129 TFLOP/s vs 134 for k_conv3x3_sd; parity-tested) ---------------
 // ---- LDS-DMA 3x3 conv for the F->F convs of an attention-free tower --------------------------------------------------------
 // Every wave is an independent worker (no workgroup barrier anywhere): 16*NPT consecutive rows x all F output channels,
 // NPT x F/16 accumulator tiles of v_mfma_f32_16x16x4_f32.  Nothing is staged through registers:
@@ -272,6 +306,9 @@ __global__ __launch_bounds__(128, 2) void k_conv3x3_dma(const float* __restrict_
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int j = lane & 15, kq = lane >> 4;
     const int m0 = (blockIdx.x * 2 + wave) * WT;
+    __shared__ __attribute__((aligned(16))) float par[3 * F];
+    for (int i = tid; i < F; i += 128) { par[i] = bias[i]; par[F + i] = out2 ? s2[i] : 0.f; par[2 * F + i] = out2 ? t2[i] : 0.f; }
+    __syncthreads();                                  // the only barrier: epilogue parameters (before any wave may leave)
     if (m0 >= M) return;
     float* slab = lds[wave];                          // [2][NROW][16]
     float* ring = slab + 2 * SLAB;                    // [NR][64 lanes][4]
@@ -360,31 +397,171 @@ __global__ __launch_bounds__(128, 2) void k_conv3x3_dma(const float* __restrict_
         }
     }
     TG_VMCNT(0);                                      // no DMA may outlive the wave's LDS
+    int mrow[NPT];
 #pragma unroll
-    for (int t = 0; t < NPT; ++t) {
-        const int m = m0 + t * 16 + j;
-        if (m >= M) continue;
+    for (int t = 0; t < NPT; ++t) mrow[t] = m0 + t * 16 + j;
+    conv_epilogue<F, CT, NPT, EPI>(acc, mrow, M, 0, kq, out, res, out2, par);
+}
+
+#ifdef TG_SD_STAMP
+__device__ unsigned long long tg_sd_dbg[8];          // diagnostic build only: summed cycles per phase, all waves
+#define TG_STAMP(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory")
+#endif
+// ---- shared-tile LDS-DMA 3x3 conv (F = 128, attention-free tower; input already activated by its producer) ----------------
+// Workgroup = 4 waves = 192 consecutive rows x all 128 output channels (wave: 3 position tiles x 8 cout tiles, 96
+// accumulator registers) -- small enough in registers (<= 168) and LDS (52.8 KB) for THREE workgroups per CU, i.e. three waves
+// per SIMD to fill each other's bubbles, and at 16384 leaves the 6912 workgroups are exactly 9 rounds of the 768 resident slots.
+// Stage g = (16-channel slice, tap): its 8-KB weight tile arrives by global_load_lds from a stage-ordered copy of the weights
+// ([slice*9+tap][cout][16]) into a 3-deep LDS ring, two stages ahead of use; the activation slab of the NEXT slice arrives by
+// buffer_load..lds (bounds check = zero fill) into the other of two slab buffers while taps 5-8 of the current one run.
+// The LDS image is XOR-swizzled at the SOURCE (a 64-B row keeps chunk c at position c ^ ((row>>2)&3); DMA destinations must
+// stay lane-linear), so the 16 rows of a ds_read_b128 fragment fall on 16 distinct 16-B slots.  One raw s_barrier per stage,
+// preceded by a counted vmcnt wait for the wave's own pieces of the next stage (DMAs retire in issue order).
+template <int S, int F, int EPI>
+__global__ __launch_bounds__(256, 3) void k_conv3x3_sd(const float* __restrict__ in, float* __restrict__ out,
+                                                       const float* __restrict__ res, const float* __restrict__ Ws,
+                                                       const float* __restrict__ bias, float* __restrict__ out2,
+                                                       const float* __restrict__ s2, const float* __restrict__ t2, int M) {
+    constexpr int P = S * S, HALO = S + 1, NPT = 3, TM = 64 * NPT, CT = 8, CC = 16;
+    constexpr int NSL = F / CC, NST = NSL * 9, D = 3;
+    constexpr int NROW = TM + 2 * HALO;               // slab rows actually needed
+    constexpr int NXP = (NROW + 15) / 16;             // DMA pieces per slab (the last one partially masked)
+    constexpr int NXQ = (NXP + 3) / 4;                // pieces issued by waves 0-2
+    constexpr int NX3 = NXP - 3 * NXQ;                // pieces issued by wave 3
+    static_assert(F == 128 && NX3 > 0 && NX3 <= NXQ, "tile geometry");
+    __shared__ __attribute__((aligned(16))) float xs[2][NROW * CC];
+    __shared__ __attribute__((aligned(16))) float ws[D][F * CC];
+    __shared__ __attribute__((aligned(16))) float par[3 * F];
+    __shared__ __attribute__((aligned(16))) float zrow[CC];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably wave-uniform (selects wait immediates)
+    const int j = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * TM;
+    if (tid < 4) *reinterpret_cast<f32x4*>(zrow + tid * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < F; i += 256) { par[i] = bias[i]; par[F + i] = out2 ? s2[i] : 0.f; par[2 * F + i] = out2 ? t2[i] : 0.f; }
+
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, M * F * 4, 0x00020000);
+    const int prow = lane >> 2, pchunk = (lane & 3) ^ (lane >> 4);      // row within a 16-row piece, swizzled source chunk
+    auto dma_x = [&](int sl, int buf) {
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            const int co = ct * 16 + kq * 4;
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + co);
-            f32x4 v = acc[ct][t] + bv;
-            if (EPI == 0) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-            } else {
-                v = v + *reinterpret_cast<const f32x4*>(res + (size_t)m * F + co);
-            }
-            *reinterpret_cast<f32x4*>(out + (size_t)m * F + co) = v;
-            if (out2) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(s2 + co), sh = *reinterpret_cast<const f32x4*>(t2 + co);
-                f32x4 u;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { float w = v[e] * sc[e] + sh[e]; u[e] = w > 0.f ? w : 0.f; }
-                *reinterpret_cast<f32x4*>(out2 + (size_t)m * F + co) = u;
+        for (int i = 0; i < NXQ; ++i) {
+            const int q = wave * NXQ + i;
+            if (q < NXP) {                                               // wave-uniform
+                const int r = q * 16 + prow;
+                if (r < NROW) {                                          // last piece: only the rows that exist
+                    const int voff = ((m0 - HALO + r) * F + sl * CC + pchunk * 4) * 4;           // outside the tensor: reads 0
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (tg_lds_void*)(&xs[buf][q * 256]), 16, voff, 0, 0, 0);
+                }
             }
         }
+    };
+    auto dma_w = [&](int g) {
+        const int gg = g < NST ? g : NST - 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pc = wave * 2 + i;
+            __builtin_amdgcn_global_load_lds(Ws + (size_t)gg * (F * CC) + (pc * 16 + prow) * CC + pchunk * 4,
+                                             (tg_lds_void*)(&ws[g % D][pc * 256]), 16, 0, 0);
+        }
+    };
+    unsigned vmask[NPT]; int vrow[NPT];
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) {
+        const int m = m0 + (wave * NPT + t) * 16 + j;
+        unsigned mk = 0;
+        if (m < M) {
+            const int p = m % P, x = p % S, y = p / S;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                if (yy >= 0 && yy < S && xx >= 0 && xx < S) mk |= 1u << tap;
+            }
+        }
+        vmask[t] = mk; vrow[t] = (wave * NPT + t) * 16 + j + HALO;
     }
+    const int aoff = j * CC + ((kq ^ ((j >> 2) & 3)) << 2);             // A fragment: row ct*16+j of the stage tile
+    auto read_b = [&](f32x4* b, int g) {
+        const int sl = g / 9, tap = g % 9;
+        const int toff = (tap / 3 - 1) * S + (tap % 3 - 1);
+        const float* base = xs[sl & 1];
+#pragma unroll
+        for (int t = 0; t < NPT; ++t) {
+            const int R = vrow[t] + toff;
+            const float* src = ((vmask[t] >> tap) & 1) ? base + R * CC + ((kq ^ ((R >> 2) & 3)) << 2) : zrow + kq * 4;
+            b[t] = *reinterpret_cast<const f32x4*>(src);
+        }
+    };
+    f32x4 acc[CT][NPT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int t = 0; t < NPT; ++t) acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#ifdef TG_SD_STAMP
+    unsigned long long t_start, t_pro, t_a, t_b, t_c, t_loop, t_end, s_dma = 0, s_bar = 0;
+    TG_STAMP(t_start);
+#endif
+    dma_x(0, 0); dma_w(0); dma_w(1);
+    TG_VMCNT(2);                                      // own pieces of X(0) and W(0) landed (W(1) may be in flight)
+    __builtin_amdgcn_s_barrier();                     // ... and everybody else's: stage 0 is visible
+#ifdef TG_SD_STAMP
+    TG_STAMP(t_pro);
+#endif
+    f32x4 b_cur[NPT], b_next[NPT];
+    read_b(b_cur, 0);
+
+    for (int g = 0; g < NST; ++g) {
+        const float* wcur = ws[g % D];
+        const int tap = g % 9;
+        const bool more = g / 9 + 1 < NSL;
+        f32x4 a_cur = *reinterpret_cast<const f32x4*>(wcur + aoff);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            f32x4 a_next = a_cur;
+            if (ct + 1 < CT) a_next = *reinterpret_cast<const f32x4*>(wcur + (ct + 1) * 256 + aoff);
+            if (ct == 4 && g + 1 < NST) read_b(b_next, g + 1);           // the slab of stage g+1 is visible (same slice, or landed by tap 6)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int t = 0; t < NPT; ++t)
+                    acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s4], b_cur[t][s4], acc[ct][t], 0, 0, 0);
+            a_cur = a_next;
+        }
+#pragma unroll
+        for (int t = 0; t < NPT; ++t) b_cur[t] = b_next[t];
+        // slot (g+2)%D held stage g-1, which every wave left before the barrier that ended it
+        dma_w(g + 2);
+        if (more && tap == 4) dma_x(g / 9 + 1, (g / 9 + 1) & 1);
+        // own pieces of W(g+1) landed?  Younger: W(g+2) (2 pieces) and, at taps 4-5, this wave's slab pieces issued after it
+#ifdef TG_SD_STAMP
+        TG_STAMP(t_a);
+#endif
+        if (more && (tap == 4 || tap == 5)) { if (wave == 3) TG_VMCNT(2 + NX3); else TG_VMCNT(2 + NXQ); }
+        else TG_VMCNT(2);
+#ifdef TG_SD_STAMP
+        TG_STAMP(t_b);
+#endif
+        __builtin_amdgcn_s_barrier();
+#ifdef TG_SD_STAMP
+        TG_STAMP(t_c);
+        s_dma += t_b - t_a; s_bar += t_c - t_b;
+#endif
+    }
+#ifdef TG_SD_STAMP
+    TG_STAMP(t_loop);
+#endif
+    TG_VMCNT(0);                                      // no DMA may outlive the workgroup's LDS
+    int mrow[NPT];
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) mrow[t] = m0 + (wave * NPT + t) * 16 + j;
+    conv_epilogue<F, CT, NPT, EPI>(acc, mrow, M, 0, kq, out, res, out2, par);
+#ifdef TG_SD_STAMP
+    TG_STAMP(t_end);
+    if (lane == 0) {
+        atomicAdd(&tg_sd_dbg[0], t_pro - t_start); atomicAdd(&tg_sd_dbg[1], s_dma); atomicAdd(&tg_sd_dbg[2], s_bar);
+        atomicAdd(&tg_sd_dbg[3], t_loop - t_pro); atomicAdd(&tg_sd_dbg[4], t_end - t_loop); atomicAdd(&tg_sd_dbg[5], 1ull);
+    }
+#endif
 }
 
 // Self_Attention core (model.py:301-315) for one board per workgroup, after the fused q/k/v 1x1 projection:
@@ -527,12 +704,21 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                 const BlockW& b = n->blocks[i];
                 const float* sn = i + 1 < nb ? n->blocks[i + 1].s1 : n->s_end;
                 const float* tn = i + 1 < nb ? n->blocks[i + 1].t1 : n->t_end;
+                const int grid_sd = (M + 191) / 192;
                 { ProfScope ps(n, st, conv_flops);
-                  hipLaunchKernelGGL((k_conv3x3_dma<S, F, 0, DNPT>), dim3(grid_d), dim3(128), 0, st, (const float*)n->bufAct, n->bufH,
-                                     (const float*)nullptr, b.f1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M); }
+                  if (n->dma == 2)
+                      hipLaunchKernelGGL((k_conv3x3_sd<S, F, 0>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufAct, n->bufH,
+                                         (const float*)nullptr, b.g1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M);
+                  else
+                      hipLaunchKernelGGL((k_conv3x3_dma<S, F, 0, DNPT>), dim3(grid_d), dim3(128), 0, st, (const float*)n->bufAct, n->bufH,
+                                         (const float*)nullptr, b.f1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M); }
                 { ProfScope ps(n, st, conv_flops);
-                  hipLaunchKernelGGL((k_conv3x3_dma<S, F, 1, DNPT>), dim3(grid_d), dim3(128), 0, st, (const float*)n->bufH, y,
-                                     (const float*)x, b.f2, b.c2.b, n->bufAct, sn, tn, M); }
+                  if (n->dma == 2)
+                      hipLaunchKernelGGL((k_conv3x3_sd<S, F, 1>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufH, y,
+                                         (const float*)x, b.g2, b.c2.b, n->bufAct, sn, tn, M);
+                  else
+                      hipLaunchKernelGGL((k_conv3x3_dma<S, F, 1, DNPT>), dim3(grid_d), dim3(128), 0, st, (const float*)n->bufH, y,
+                                         (const float*)x, b.f2, b.c2.b, n->bufAct, sn, tn, M); }
                 float* t = x; x = y; y = t;
             }
             hipLaunchKernelGGL((k_conv3x3<S, F, 16, false, 0>), dim3(grid), dim3(256), 0, st, (const float*)n->bufAct, n->hc,
@@ -681,9 +867,10 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
         TG_HIP(ctx, hipMalloc((void**)&n->hc, sizeof(float) * (size_t)rows_cap * P * 16));
         TG_HIP(ctx, hipMalloc((void**)&n->own, sizeof(float) * (size_t)rows_cap * P));
         TG_HIP(ctx, hipMalloc((void**)&n->frag, sizeof(float) * (size_t)(NB > 0 ? 2 * NB : 1) * 9 * F * F));
+        TG_HIP(ctx, hipMalloc((void**)&n->wstage, sizeof(float) * (size_t)(NB > 0 ? 2 * NB : 1) * 9 * F * F));
         if (any_att) TG_HIP(ctx, hipMalloc((void**)&n->bufQ, sizeof(float) * (size_t)rows_cap * P * Wq));
         if (pol) TG_HIP(ctx, hipMalloc((void**)&n->hca, sizeof(float) * (size_t)rows_cap * P * 16));
-        n->dma = !any_att && F == 128 && getenv("TG_DMA_CONV") != nullptr;   // opt-in alternative (129 vs 132 TFLOP/s)
+        n->dma = (!any_att && F == 128) ? (getenv("TG_DMA_CONV") ? atoi(getenv("TG_DMA_CONV")) : 2) : 0;   // 2 = k_conv3x3_sd (default), 1 = k_conv3x3_dma, 0 = k_conv3x3
         if (n->dma) TG_HIP(ctx, hipMalloc((void**)&n->bufAct, act));
         const float* p = n->blob;
         auto take = [&](size_t k) { const float* q = p; p += k; return q; };
@@ -698,7 +885,7 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
                 b.s1 = take(F); b.t1 = take(F);
                 b.c1.w = take(9 * (size_t)F * F); b.c1.b = take(F);
                 b.c2.w = take(9 * (size_t)F * F); b.c2.b = take(F);
-                b.f1 = b.f2 = nullptr;
+                b.f1 = b.f2 = b.g1 = b.g2 = nullptr;
             } else {
                 take_att(L.a);
             }
@@ -744,14 +931,28 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
                                             w[((size_t)tap * F + (cg * CTW + ct) * 16 + (lane & 15)) * F + sl * WCC + sub * 16 + (lane >> 4) * 4 + e];
                             }
         };
+        // stage-ordered copy for k_conv3x3_sd: [slice*9 + tap][cout][16 channels of the slice]
+        std::vector<float> sg(fr.size());
+        auto restage = [&](const float* w, float* dst) {
+            for (int sl = 0; sl < F / 16; ++sl)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int co = 0; co < F; ++co)
+                        for (int c = 0; c < 16; ++c)
+                            dst[(((size_t)sl * 9 + tap) * F + co) * 16 + c] = w[((size_t)tap * F + co) * F + sl * 16 + c];
+        };
         for (size_t i = 0; i < n->blocks.size(); ++i) {
             BlockW& b = n->blocks[i];
             repack(blob + (b.c1.w - n->blob), fr.data() + (2 * i) * per);
             repack(blob + (b.c2.w - n->blob), fr.data() + (2 * i + 1) * per);
+            restage(blob + (b.c1.w - n->blob), sg.data() + (2 * i) * per);
+            restage(blob + (b.c2.w - n->blob), sg.data() + (2 * i + 1) * per);
             b.f1 = n->frag + (2 * i) * per; b.f2 = n->frag + (2 * i + 1) * per;
+            b.g1 = n->wstage + (2 * i) * per; b.g2 = n->wstage + (2 * i + 1) * per;
         }
-        if (!n->blocks.empty())
+        if (!n->blocks.empty()) {
             TG_HIP(ctx, hipMemcpyAsync(n->frag, fr.data(), sizeof(float) * fr.size(), hipMemcpyHostToDevice, ctx->stream));
+            TG_HIP(ctx, hipMemcpyAsync(n->wstage, sg.data(), sizeof(float) * sg.size(), hipMemcpyHostToDevice, ctx->stream));
+        }
         TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return TG_OK;
@@ -760,7 +961,7 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
 void tg_net_destroy(tg_ctx* ctx) {
     if (!ctx || !ctx->eng || !ctx->eng->net) return;
     Net* n = ctx->eng->net;
-    void* ptrs[] = {n->blob, n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->frag, n->bufQ, n->hca, n->bufAct};
+    void* ptrs[] = {n->blob, n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->frag, n->bufQ, n->hca, n->bufAct, n->wstage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t ev : n->ev) (void)hipEventDestroy(ev);
     delete n;
@@ -797,6 +998,15 @@ int tg_net_predict(tg_ctx* ctx, const float* obs, int n_rows, float* policy, flo
     }
     return TG_OK;
 }
+
+#ifdef TG_SD_STAMP
+int tg_dbg_read(unsigned long long* out8) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(tg_sd_dbg), sizeof(z)) != hipSuccess) return -1;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(tg_sd_dbg), z, sizeof(z));
+    return 0;
+}
+#endif
 
 // HIP-event timing of the dominant kernel (3x3 conv F->F), measured on the stream the kernels are launched on.
 int tg_prof_enable(tg_ctx* ctx, int on, int max_launches) {

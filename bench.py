@@ -174,7 +174,9 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": PEAK_F32_MATRIX_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(conv_tflops / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": traffic,
                          "traffic_note": "HBM bytes per full-batch launch, FETCH_SIZE x2 + WRITE_SIZE (profiles/r1_pmc_traffic.json)",
-                         "kernel": f"k_conv3x3<{S},{a.filters},{a.filters}> (fp32 MFMA 16x16x4 implicit GEMM)",
+                         "kernel": (f"k_conv3x3_sd<{S},128> (fp32 MFMA 16x16x4 implicit GEMM, LDS-DMA fed)" if a.filters == 128 and
+                                    os.environ.get("TG_DMA_CONV", "2") == "2" else
+                                    f"k_conv3x3<{S},{a.filters},{a.filters}> (fp32 MFMA 16x16x4 implicit GEMM)"),
                          "launches": int(nl.value), "avg_launch_ms": round(ms.value / max(1, nl.value), 4)},
             "cpu_baseline": cpu,
             "extra": {"leaves_per_s": round(evals_all / dt, 1), "mean_depth": round(depth_all / max(1.0, sims_all), 3),

@@ -687,8 +687,6 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
     const double conv_flops = 2.0 * 9.0 * (double)F * (double)F * (double)M;
     int g0 = (int)(((size_t)M * 16 + 255) / 256); if (g0 > 65535) g0 = 65535;
     hipLaunchKernelGGL((k_obs_to_rows<S>), dim3(g0), dim3(256), 0, st, obs, n->x0, rows, n->C);
-    hipLaunchKernelGGL((k_conv3x3<S, 16, F, false, 0>), dim3(grid), dim3(256), 0, st, (const float*)n->x0, n->bufA,
-                       (const float*)nullptr, n->stem.w, n->stem.b, (const float*)nullptr, (const float*)nullptr, M);
     float* x = n->bufA; float* y = n->bufB;
     if constexpr (F == 128) {
         if (n->dma && (long long)M * F * 4 < (1ll << 31)) {
@@ -729,6 +727,8 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
             return TG_OK;
         }
     }
+    hipLaunchKernelGGL((k_conv3x3<S, 16, F, false, 0>), dim3(grid), dim3(256), 0, st, (const float*)n->x0, x,
+                       (const float*)nullptr, n->stem.w, n->stem.b, (const float*)nullptr, (const float*)nullptr, M);
     // attention block: fused q|k|v 1x1 projection on the matrix cores, then the per-board core (model.py:301-315)
     constexpr int W = F / 4 + F / 4 + F;
     constexpr size_t att_lds = sizeof(float) * ((size_t)P * W + (size_t)P * (P + 1));

@@ -503,6 +503,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_sd(const float* __restrict__
 #endif
     dma_x(0, 0); dma_w(0); dma_w(1);
     TG_VMCNT(2);                                      // own pieces of X(0) and W(0) landed (W(1) may be in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // own ds_writes (zero row, epilogue parameters) retired
     __builtin_amdgcn_s_barrier();                     // ... and everybody else's: stage 0 is visible
 #ifdef TG_SD_STAMP
     TG_STAMP(t_pro);

@@ -22,7 +22,8 @@ def _positions(S, n, seed):
     return np.stack(obs)
 
 
-@pytest.mark.parametrize("S,F,NB,n", [(9, 32, 2, 300), (9, 128, 6, 257), (9, 64, 3, 5), (19, 128, 2, 9)])
+@pytest.mark.parametrize("S,F,NB,n", [(9, 32, 2, 300), (9, 128, 6, 257), (9, 64, 3, 5), (19, 128, 2, 9),
+                                       (9, 256, 2, 131), (19, 256, 2, 7)])
 def test_tower_matches_torch(S, F, NB, n):
     import torch
     from oracle.net import seeded_tower

@@ -407,10 +407,11 @@ __global__ __launch_bounds__(128, 2) void k_conv3x3_dma(const float* __restrict_
 __device__ unsigned long long tg_sd_dbg[8];          // diagnostic build only: summed cycles per phase, all waves
 #define TG_STAMP(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory")
 #endif
-// ---- shared-tile LDS-DMA 3x3 conv (F = 128, attention-free tower; input already activated by its producer) ----------------
-// Workgroup = 4 waves = 192 consecutive rows x all 128 output channels (wave: 3 position tiles x 8 cout tiles, 96
+// ---- shared-tile LDS-DMA 3x3 conv (F = 128 / 256, attention-free tower; input already activated by its producer) ----------------
+// F = 128: workgroup = 4 waves = 192 consecutive rows x all 128 output channels (wave: 3 position tiles x 8 cout tiles, 96
 // accumulator registers) -- small enough in registers (<= 168) and LDS (52.8 KB) for THREE workgroups per CU, i.e. three waves
 // per SIMD to fill each other's bubbles, and at 16384 leaves the 6912 workgroups are exactly 9 rounds of the 768 resident slots.
+// F = 256: 128 rows x 256 channels (2 x 16 tiles, 128 accumulators), two workgroups per CU.
 // Stage g = (16-channel slice, tap): its 8-KB weight tile arrives by global_load_lds from a stage-ordered copy of the weights
 // ([slice*9+tap][cout][16]) into a 3-deep LDS ring, two stages ahead of use; the activation slab of the NEXT slice arrives by
 // buffer_load..lds (bounds check = zero fill) into the other of two slab buffers while taps 5-8 of the current one run.
@@ -418,17 +419,19 @@ __device__ unsigned long long tg_sd_dbg[8];          // diagnostic build only: s
 // stay lane-linear), so the 16 rows of a ds_read_b128 fragment fall on 16 distinct 16-B slots.  One raw s_barrier per stage,
 // preceded by a counted vmcnt wait for the wave's own pieces of the next stage (DMAs retire in issue order).
 template <int S, int F, int EPI>
-__global__ __launch_bounds__(256, 3) void k_conv3x3_sd(const float* __restrict__ in, float* __restrict__ out,
+__global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sd(const float* __restrict__ in, float* __restrict__ out,
                                                        const float* __restrict__ res, const float* __restrict__ Ws,
                                                        const float* __restrict__ bias, float* __restrict__ out2,
                                                        const float* __restrict__ s2, const float* __restrict__ t2, int M) {
-    constexpr int P = S * S, HALO = S + 1, NPT = 3, TM = 64 * NPT, CT = 8, CC = 16;
+    constexpr int P = S * S, HALO = S + 1, CT = F / 16, CC = 16;
+    constexpr int NPT = F == 128 ? 3 : 2, TM = 64 * NPT;        // accumulators: CT*NPT*4 = 96 (F=128) / 128 (F=256) registers
+    constexpr int WPW = CT / 4;                                  // weight pieces (16 couts x 16 channels) per wave per stage
     constexpr int NSL = F / CC, NST = NSL * 9, D = 3;
     constexpr int NROW = TM + 2 * HALO;               // slab rows actually needed
     constexpr int NXP = (NROW + 15) / 16;             // DMA pieces per slab (the last one partially masked)
     constexpr int NXQ = (NXP + 3) / 4;                // pieces issued by waves 0-2
     constexpr int NX3 = NXP - 3 * NXQ;                // pieces issued by wave 3
-    static_assert(F == 128 && NX3 > 0 && NX3 <= NXQ, "tile geometry");
+    static_assert((F == 128 || F == 256) && NX3 > 0 && NX3 <= NXQ, "tile geometry");
     __shared__ __attribute__((aligned(16))) float xs[2][NROW * CC];
     __shared__ __attribute__((aligned(16))) float ws[D][F * CC];
     __shared__ __attribute__((aligned(16))) float par[3 * F];
@@ -458,8 +461,8 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_sd(const float* __restrict__
     auto dma_w = [&](int g) {
         const int gg = g < NST ? g : NST - 1;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int pc = wave * 2 + i;
+        for (int i = 0; i < WPW; ++i) {
+            const int pc = wave * WPW + i;
             __builtin_amdgcn_global_load_lds(Ws + (size_t)gg * (F * CC) + (pc * 16 + prow) * CC + pchunk * 4,
                                              (tg_lds_void*)(&ws[g % D][pc * 256]), 16, 0, 0);
         }
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_sd(const float* __restrict__
     TG_STAMP(t_start);
 #endif
     dma_x(0, 0); dma_w(0); dma_w(1);
-    TG_VMCNT(2);                                      // own pieces of X(0) and W(0) landed (W(1) may be in flight)
+    TG_VMCNT(WPW);                                    // own pieces of X(0) and W(0) landed (W(1) may be in flight)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // own ds_writes (zero row, epilogue parameters) retired
     __builtin_amdgcn_s_barrier();                     // ... and everybody else's: stage 0 is visible
 #ifdef TG_SD_STAMP
@@ -533,12 +536,12 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_sd(const float* __restrict__
         // slot (g+2)%D held stage g-1, which every wave left before the barrier that ended it
         dma_w(g + 2);
         if (more && tap == 4) dma_x(g / 9 + 1, (g / 9 + 1) & 1);
-        // own pieces of W(g+1) landed?  Younger: W(g+2) (2 pieces) and, at taps 4-5, this wave's slab pieces issued after it
+        // own pieces of W(g+1) landed?  Younger: W(g+2) (WPW pieces) and, at taps 4-5, this wave's slab pieces issued after it
 #ifdef TG_SD_STAMP
         TG_STAMP(t_a);
 #endif
-        if (more && (tap == 4 || tap == 5)) { if (wave == 3) TG_VMCNT(2 + NX3); else TG_VMCNT(2 + NXQ); }
-        else TG_VMCNT(2);
+        if (more && (tap == 4 || tap == 5)) { if (wave == 3) TG_VMCNT(WPW + NX3); else TG_VMCNT(WPW + NXQ); }
+        else TG_VMCNT(WPW);
 #ifdef TG_SD_STAMP
         TG_STAMP(t_b);
 #endif
@@ -689,7 +692,7 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
     int g0 = (int)(((size_t)M * 16 + 255) / 256); if (g0 > 65535) g0 = 65535;
     hipLaunchKernelGGL((k_obs_to_rows<S>), dim3(g0), dim3(256), 0, st, obs, n->x0, rows, n->C);
     float* x = n->bufA; float* y = n->bufB;
-    if constexpr (F == 128) {
+    if constexpr (F == 128 || F == 256) {
         if (n->dma && (long long)M * F * 4 < (1ll << 31)) {
             // prologue-free chain: every producer also writes relu(bn_next(.)) for its consumer
             constexpr int DNPT = TG_DMA_NPT;
@@ -703,19 +706,20 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                 const BlockW& b = n->blocks[i];
                 const float* sn = i + 1 < nb ? n->blocks[i + 1].s1 : n->s_end;
                 const float* tn = i + 1 < nb ? n->blocks[i + 1].t1 : n->t_end;
-                const int grid_sd = (M + 191) / 192;
+                constexpr int SD_TM = F == 128 ? 192 : 128;
+                const int grid_sd = (M + SD_TM - 1) / SD_TM;
                 { ProfScope ps(n, st, conv_flops);
                   if (n->dma == 2)
                       hipLaunchKernelGGL((k_conv3x3_sd<S, F, 0>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufAct, n->bufH,
                                          (const float*)nullptr, b.g1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M);
-                  else
+                  else if constexpr (F == 128)
                       hipLaunchKernelGGL((k_conv3x3_dma<S, F, 0, DNPT>), dim3(grid_d), dim3(128), 0, st, (const float*)n->bufAct, n->bufH,
                                          (const float*)nullptr, b.f1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M); }
                 { ProfScope ps(n, st, conv_flops);
                   if (n->dma == 2)
                       hipLaunchKernelGGL((k_conv3x3_sd<S, F, 1>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufH, y,
                                          (const float*)x, b.g2, b.c2.b, n->bufAct, sn, tn, M);
-                  else
+                  else if constexpr (F == 128)
                       hipLaunchKernelGGL((k_conv3x3_dma<S, F, 1, DNPT>), dim3(grid_d), dim3(128), 0, st, (const float*)n->bufH, y,
                                          (const float*)x, b.f2, b.c2.b, n->bufAct, sn, tn, M); }
                 float* t = x; x = y; y = t;
@@ -871,7 +875,8 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
         TG_HIP(ctx, hipMalloc((void**)&n->wstage, sizeof(float) * (size_t)(NB > 0 ? 2 * NB : 1) * 9 * F * F));
         if (any_att) TG_HIP(ctx, hipMalloc((void**)&n->bufQ, sizeof(float) * (size_t)rows_cap * P * Wq));
         if (pol) TG_HIP(ctx, hipMalloc((void**)&n->hca, sizeof(float) * (size_t)rows_cap * P * 16));
-        n->dma = (!any_att && F == 128) ? (getenv("TG_DMA_CONV") ? atoi(getenv("TG_DMA_CONV")) : 2) : 0;   // 2 = k_conv3x3_sd (default), 1 = k_conv3x3_dma, 0 = k_conv3x3
+        n->dma = (!any_att && (F == 128 || F == 256)) ? (getenv("TG_DMA_CONV") ? atoi(getenv("TG_DMA_CONV")) : 2) : 0;
+        if (F == 256 && n->dma == 1) n->dma = 2;    // the wave-private variant exists for F = 128 only   // 2 = k_conv3x3_sd (default), 1 = k_conv3x3_dma, 0 = k_conv3x3
         if (n->dma) TG_HIP(ctx, hipMalloc((void**)&n->bufAct, act));
         const float* p = n->blob;
         auto take = [&](size_t k) { const float* q = p; p += k; return q; };

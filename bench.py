@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, dense fp32 matrix peak
+PEAK_F16_MATRIX_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense F16/BF16 MFMA (v_mfma_f32_16x16x32_f16), ~2.5 PFLOP/s
 
 
 def flops_per_leaf(S, C, F, N):
@@ -83,6 +84,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=6)
     ap.add_argument("--board", type=int, default=9, help="board edge (9 = BASELINE configs[1]; 19 = configs[3])")
     ap.add_argument("--max-step", type=int, default=0, help="ply limit (default 120 at 9x9, 450 at 19x19)")
+    ap.add_argument("--dtype", choices=["f32", "f16"], default="f32",
+                    help="network arithmetic: f32 (BASELINE metric, parity 1e-3) or f16 storage + f32 accumulate (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     a = ap.parse_args()
@@ -116,7 +119,7 @@ def main():
 
     S = a.board
     cfg = Config(num_simulation=a.sims, num_features=a.filters, num_blocks=a.blocks, board_size=S,
-                 max_step=a.max_step or (120 if S == 9 else 450))
+                 max_step=a.max_step or (120 if S == 9 else 450), inference_dtype=a.dtype)
     sp = BatchedSelfPlay(cfg, a.games, device=local if backend == "nccl" else 0, rank=rank, world=world)
     sp.set_weights(model.random_weights(S, 10, a.filters, a.blocks, seed=1234))
     sp.start()
@@ -157,22 +160,23 @@ def main():
         # they only describe the configuration they were collected on
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-        if os.path.exists(tfile) and (S, a.filters, a.games) == (9, 128, 4096):
+        if os.path.exists(tfile) and (S, a.filters, a.games, a.dtype) == (9, 128, 4096, "f32"):
             with open(tfile) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch_mean")
         value = sims_all / dt
         conv_tflops = (fl.value / (ms.value * 1e-3)) / 1e12 if ms.value > 0 else 0.0
         fpl = flops_per_leaf(S, 10, a.filters, a.blocks)
+        peak = PEAK_F16_MATRIX_TFLOPS if a.dtype == "f16" else PEAK_F32_MATRIX_TFLOPS
         line = {
             "metric": "MCTS simulations/sec", "value": round(value, 1), "unit": "sims/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"{S}x{S} Go self-play, {a.sims} sims/move, {a.blocks}-block x {a.filters}-filter tower, "
                                    f"{a.games} concurrent boards per GPU", "boards_per_gpu": a.games,
                        "parallelism": f"games sharded over {world} GPU(s), no data-path collective",
                        "step": "one move of every board (search + move selection + re-root + gather of finished games)"},
-            "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": PEAK_F32_MATRIX_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(conv_tflops / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": traffic,
+            "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(conv_tflops / peak, 4), "traffic": traffic,
                          "traffic_note": "HBM bytes per full-batch launch, FETCH_SIZE x2 + WRITE_SIZE (profiles/r1_pmc_traffic.json)",
                          "kernel": (f"k_conv3x3_sd<{S},128> (fp32 MFMA 16x16x4 implicit GEMM, LDS-DMA fed)" if a.filters == 128 and
                                     os.environ.get("TG_DMA_CONV", "2") == "2" else

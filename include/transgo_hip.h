@@ -54,7 +54,8 @@ typedef struct tg_config {
     int32_t net_blocks;         /* residual blocks of the tower (BASELINE.json "N-block x F-filter") */
     int32_t net_filters;        /* channels F (multiple of 32) */
     int32_t device;             /* HIP device ordinal */
-    int32_t reserved[8];
+    int32_t net_precision;      /* 0 = f32 network (default); 1 = fp16 weights/activations, f32 accumulate (BASELINE config 5) */
+    int32_t reserved[7];
 } tg_config;
 
 void tg_config_default(tg_config* cfg);

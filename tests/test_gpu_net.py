@@ -126,3 +126,37 @@ def test_dma_conv_path_matches_torch(monkeypatch, variant):
         h.set_weights(net.get_weights())
         hp, hv, ho = h.main_prediction(x)
         assert np.abs(hp - p.numpy()).max() < TOL and np.abs(hv - v.numpy()).max() < TOL and np.abs(ho - o.numpy()).max() < TOL
+
+
+@pytest.mark.parametrize("S,F,NB,n", [(9, 256, 3, 70), (19, 256, 2, 5), (9, 128, 4, 40), (19, 128, 1, 3)])
+def test_fp16_chain_matches_half_storage_oracle(S, F, NB, n):
+    """BASELINE config 5 ("fp16 policy/value inference"): fp16 weights/activations, f32 accumulate (k_conv3x3_h).  Checked
+    against the oracle's emulation with the same rounding points (only the summation order inside a conv is free: 1e-3),
+    and reported / bounded against the plain f32 network (expect <~5e-3 on the probabilities)."""
+    import torch
+    from oracle.net import half_storage_forward, seeded_tower
+    from transgo_amd.model import HipNetwork
+    torch.set_num_threads(4)
+    net = seeded_tower(S, 10, F, NB, seed=77 + F)
+    x = _positions(S, n, 5)
+    p16, v16, o16 = [t.numpy() for t in half_storage_forward(net, torch.from_numpy(x))]
+    with torch.no_grad():
+        p32, v32, o32 = [t.numpy() for t in net.main_prediction(torch.from_numpy(x))]
+    h = HipNetwork(S, 10, F, NB, rows_cap=32, precision="f16")        # smaller than n: chunking; 32 boards < one 256-row tile at 9x9
+    h.set_weights(net.get_weights())
+    hp, hv, ho = h.main_prediction(x)
+    e16 = [np.abs(a - b).max() for a, b in ((hp, p16), (hv, v16), (ho, o16))]
+    e32 = [np.abs(a - b).max() for a, b in ((hp, p32), (hv, v32), (ho, o32))]
+    print(f"fp16 S={S} F={F} N={NB}: vs half-storage oracle policy {e16[0]:.2e} value {e16[1]:.2e} own {e16[2]:.2e}; "
+          f"vs f32 network policy {e32[0]:.2e} value {e32[1]:.2e} own {e32[2]:.2e}")
+    assert max(e16) < TOL
+    assert e32[0] < 5e-3 and e32[1] < 2e-2 and e32[2] < 2e-2
+    assert np.allclose(hp.sum(1), 1.0, atol=1e-5)
+
+
+def test_fp16_refused_where_not_built():
+    from transgo_amd._lib import TransgoError
+    from transgo_amd.model import HipNetwork, random_weights
+    h = HipNetwork(9, 10, 64, 2, rows_cap=8, precision="f16")
+    with pytest.raises(TransgoError):
+        h.set_weights(random_weights(9, 10, 64, 2))

@@ -14,7 +14,8 @@ class TgConfig(ctypes.Structure):
                 ("komi", ctypes.c_float), ("n_games", ctypes.c_int32), ("num_simulation", ctypes.c_int32),
                 ("parallel_readouts", ctypes.c_int32), ("wu_loss", ctypes.c_int32), ("c_puct1", ctypes.c_double),
                 ("c_puct2", ctypes.c_double), ("arena_slots", ctypes.c_int32), ("net_blocks", ctypes.c_int32),
-                ("net_filters", ctypes.c_int32), ("device", ctypes.c_int32), ("reserved", ctypes.c_int32 * 8)]
+                ("net_filters", ctypes.c_int32), ("device", ctypes.c_int32), ("net_precision", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 7)]
 
 
 class TgMt19937(ctypes.Structure):

@@ -26,7 +26,8 @@ using namespace tg;
 namespace tg {
 
 struct ConvW { const float* w; const float* b; };
-struct BlockW { const float* s1; const float* t1; ConvW c1; ConvW c2; const float* f1; const float* f2; const float* g1; const float* g2; };   // f1/f2: fragment-ordered copies
+struct BlockW { const float* s1; const float* t1; ConvW c1; ConvW c2; const float* f1; const float* f2; const float* g1; const float* g2;
+                const _Float16* h1; const _Float16* h2; };   // f1/f2: fragment-ordered, g1/g2: stage-ordered f32, h1/h2: stage-ordered fp16 copies
 struct AttW { ConvW qkv; const float* gamma; const float* s; const float* t; };      // Self_Attention, model.py:288-315
 struct Layer { int kind; int ridx; AttW a; };                                         // kind 0: residual block blocks[ridx]; 1: attention
 
@@ -39,6 +40,8 @@ struct Net {
     bool pol_att = false; AttW patt; ConvW head_a; std::string arch;
     float* bufQ = nullptr; float* hca = nullptr;   // q|k|v projections [rows][P][1.5F]; policy head conv output
     float* bufAct = nullptr;                       // pre-activated input of the next conv (DMA path)
+    int prec = 0;                                  // cfg.net_precision: 0 = f32, 1 = fp16 storage + f32 accumulate (k_conv3x3_h)
+    _Float16* wh = nullptr; _Float16* act16 = nullptr; _Float16* h16 = nullptr;   // fp16 path: weights [2*NB][F/64*9][F][64], activations [rows][P][F]
     int dma = 0;                                   // attention-free F=128 tower: 2 = k_conv3x3_sd (default), 1 = k_conv3x3_dma, 0 = k_conv3x3
     ConvW head; const float* w_vo = nullptr; const float* b_vo = nullptr; const float* w_v = nullptr; const float* b_v = nullptr;
     const float* w_o = nullptr; const float* b_o = nullptr; const float* w_a = nullptr; const float* b_a = nullptr;
@@ -568,6 +571,237 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sd(const fl
 #endif
 }
 
+// ---- fp16-storage 3x3 conv (BASELINE config 5: "fp16 policy/value inference"; f32 accumulate) ---------------------------------
+// Activations and weights are _Float16 in HBM and LDS, products accumulate in f32 on v_mfma_f32_16x16x32_f16 (16x the f32 MFMA
+// rate), so the kernel is shaped by what feeds the pipe rather than by the pipe: a workgroup computes 64*WPOS rows x ALL F
+// couts (at F=256: 8 waves = 2 cout halves x 4 position quarters, wave tile 128 couts x 64 rows = 8x4 accumulator tiles), which
+// makes the weight stream from L2 1.18 MB per 256 rows (~4 TB/s chip-wide at 1 PFLOP/s) and the LDS operand reads 12 b128 per
+// 32 MFMAs (~37 % of the LDS array).  Stage g = (KC-channel slice, tap): its F x KC weight tile arrives by global_load_lds into
+// a 2-deep ring one stage ahead; the slab of the next slice (rows + halo, KC channels) arrives during taps 0-1 of the current
+// one.  Rows are KC halfs (128 B at KC=64) with 16-B chunk c of row r stored at c ^ ((r / RP) % NCHK) (RP = rows per 256 B), the
+// XOR applied at the DMA source; a fragment read is lane (j, kq) -> row j, chunk 4*kstep + kq, the operand layout of the MFMA.
+// EPI 0: out16 = half(relu(acc + bias))     EPI 1: out32 = acc + bias + res ; out16 = half(relu(out32 * s2 + t2)) (optional)
+using h8 = __attribute__((ext_vector_type(8))) _Float16;
+using h4 = __attribute__((ext_vector_type(4))) _Float16;
+
+// s_waitcnt vmcnt(n) for a wave-uniform n in [0, N]: the instruction takes an immediate
+template <int N>
+__device__ __forceinline__ void vmcnt_uniform(int n) {
+    if (n >= N) TG_VMCNT(N);
+    else if constexpr (N > 0) vmcnt_uniform<N - 1>(n);
+}
+
+template <int F, int CT, int NPT, int EPI>
+__device__ __forceinline__ void conv_epilogue_h(f32x4 (&acc)[CT][NPT], const int (&mrow)[NPT], int M, int co_base, int kq,
+                                                float* __restrict__ out32, _Float16* __restrict__ out16,
+                                                const float* __restrict__ res, const float* par) {
+    constexpr int CH = 4, NCH = (CT / CH) * NPT;
+    static_assert(CT % CH == 0, "chunking");
+    f32x4 r[2][CH];
+    auto load_res = [&](int c, f32x4* dst) {
+        const int t = c / (CT / CH), h = c % (CT / CH);
+        if (mrow[t] < M) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+                dst[i] = *reinterpret_cast<const f32x4*>(res + (size_t)mrow[t] * F + co_base + (h * CH + i) * 16 + kq * 4);
+        }
+    };
+    if (EPI == 1) load_res(0, r[0]);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int t = c / (CT / CH), h = c % (CT / CH);
+        if (EPI == 1 && c + 1 < NCH) load_res(c + 1, r[(c + 1) & 1]);
+        if (mrow[t] < M) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int col = co_base + (h * CH + i) * 16 + kq * 4;
+                f32x4 v = acc[h * CH + i][t] + *reinterpret_cast<const f32x4*>(par + col);
+                h4 u;
+                if (EPI == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) u[e] = (_Float16)(v[e] > 0.f ? v[e] : 0.f);
+                    *reinterpret_cast<h4*>(out16 + (size_t)mrow[t] * F + col) = u;
+                } else {
+                    v = v + r[c & 1][i];
+                    *reinterpret_cast<f32x4*>(out32 + (size_t)mrow[t] * F + col) = v;
+                    if (out16) {
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(par + F + col);
+                        const f32x4 sh = *reinterpret_cast<const f32x4*>(par + 2 * F + col);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float w = v[e] * sc[e] + sh[e]; u[e] = (_Float16)(w > 0.f ? w : 0.f); }
+                        *reinterpret_cast<h4*>(out16 + (size_t)mrow[t] * F + col) = u;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int S, int F, int EPI, int KC, int WCO, int WPOS>
+__global__ __launch_bounds__(64 * WCO * WPOS, 1) void k_conv3x3_h(const _Float16* __restrict__ in, float* __restrict__ out32,
+                                                                  _Float16* __restrict__ out16, const float* __restrict__ res,
+                                                                  const _Float16* __restrict__ Ws, const float* __restrict__ bias,
+                                                                  const float* __restrict__ s2, const float* __restrict__ t2, int M) {
+    constexpr int P = S * S, HALO = S + 1, NW = WCO * WPOS, NT = 64 * NW, NPT = 4, TM = 64 * WPOS, CT = F / 16 / WCO;
+    constexpr int NCHK = KC / 8;                      // 16-B chunks per row
+    constexpr int RP = 16 / NCHK;                     // rows per 256 B of LDS
+    constexpr int RPP = 64 / NCHK;                    // rows per 1-KB DMA piece
+    constexpr int NSL = F / KC, NST = NSL * 9, KS = KC / 32;
+    constexpr int NROW = TM + 2 * HALO;
+    constexpr int NXP = (NROW + RPP - 1) / RPP;       // DMA pieces per slab
+    constexpr int NXQ = (NXP + NW - 1) / NW;          // ... issued by waves 0..NW-2
+    constexpr int NWP = F / RPP, WPW = NWP / NW;      // weight pieces per stage / per wave
+    static_assert(KC == 32 || KC == 64, "row = 64 or 128 bytes");
+    static_assert(NXQ <= 16 && NWP % NW == 0 && F % KC == 0 && CT % 4 == 0, "tile geometry");
+    __shared__ __attribute__((aligned(16))) _Float16 xs[2][NXP * RPP * KC];
+    __shared__ __attribute__((aligned(16))) _Float16 ws[2][F * KC];
+    __shared__ __attribute__((aligned(16))) float par[3 * F];
+    __shared__ __attribute__((aligned(16))) float zrow[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave / WPOS, wpos = wave % WPOS;
+    const int nx_mine = NXP - wave * NXQ < 0 ? 0 : NXP - wave * NXQ > NXQ ? NXQ : NXP - wave * NXQ;   // this wave's slab pieces
+    const int j = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * TM;
+    if (tid < 4) zrow[tid] = 0.f;
+    for (int i = tid; i < F; i += NT) { par[i] = bias[i]; par[F + i] = out16 && s2 ? s2[i] : 0.f; par[2 * F + i] = out16 && t2 ? t2[i] : 0.f; }
+
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in), 0, M * F * 2, 0x00020000);
+    const int prow = lane / NCHK, pchk = lane % NCHK;
+    auto dma_x = [&](int sl, int buf) {
+#pragma unroll
+        for (int i = 0; i < NXQ; ++i) {
+            const int q = wave * NXQ + i;
+            if (q < NXP) {                                               // wave-uniform
+                const int r = q * RPP + prow;
+                if (r < NROW) {
+                    const int lc = pchk ^ ((r / RP) % NCHK);             // logical chunk stored at physical position pchk
+                    const int voff = ((m0 - HALO + r) * F + sl * KC + lc * 8) * 2;       // outside the tensor: reads 0
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (tg_lds_void*)(&xs[buf][q * 512]), 16, voff, 0, 0, 0);
+                }
+            }
+        }
+    };
+    auto dma_w = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            const int pc = wave * WPW + i;
+            const int r = pc * RPP + prow;
+            const int lc = pchk ^ ((r / RP) % NCHK);
+            __builtin_amdgcn_global_load_lds(Ws + ((size_t)g * F + r) * KC + lc * 8, (tg_lds_void*)(&ws[g & 1][pc * 512]), 16, 0, 0);
+        }
+    };
+    unsigned vmask[NPT]; int vrow[NPT];
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) {
+        const int m = m0 + (wpos * NPT + t) * 16 + j;
+        unsigned mk = 0;
+        if (m < M) {
+            const int p = m % P, x = p % S, y = p / S;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                if (yy >= 0 && yy < S && xx >= 0 && xx < S) mk |= 1u << tap;
+            }
+        }
+        vmask[t] = mk; vrow[t] = (wpos * NPT + t) * 16 + j + HALO;
+    }
+    const int arow = wco * CT * 16 + j;                                  // A fragment: cout row of tile ct = arow + ct*16
+    const int asw = (j / RP) % NCHK;
+    auto read_a = [&](const _Float16* wcur, int ct, int ks) {
+        return *reinterpret_cast<const f32x4*>(wcur + (arow + ct * 16) * KC + (((ks * 4 + kq) ^ asw) << 3));
+    };
+    auto read_b = [&](f32x4* b, int g, int ks) {
+        const int sl = g / 9, tap = g % 9;
+        const int toff = (tap / 3 - 1) * S + (tap % 3 - 1);
+        const _Float16* base = xs[sl & 1];
+#pragma unroll
+        for (int t = 0; t < NPT; ++t) {
+            const int R = vrow[t] + toff;
+            const _Float16* src = ((vmask[t] >> tap) & 1) ? base + R * KC + (((ks * 4 + kq) ^ ((R / RP) % NCHK)) << 3)
+                                                          : reinterpret_cast<const _Float16*>(zrow);
+            b[t] = *reinterpret_cast<const f32x4*>(src);
+        }
+    };
+    f32x4 acc[CT][NPT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int t = 0; t < NPT; ++t) acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    dma_x(0, 0); dma_w(0);
+    TG_VMCNT(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    f32x4 b_cur[NPT], b_next[NPT];
+    read_b(b_cur, 0, 0);
+
+    for (int g = 0; g < NST; ++g) {
+        const _Float16* wcur = ws[g & 1];
+        const int tap = g % 9;
+        const bool more = g / 9 + 1 < NSL;
+        // slot (g+1)&1 held stage g-1, and slab buffer (slice+1)&1 the previous slice: every wave left them before the last barrier
+        if (g + 1 < NST) dma_w(g + 1);
+        if (more && tap == 0) dma_x(g / 9 + 1, (g / 9 + 1) & 1);
+        f32x4 a_cur = read_a(wcur, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                f32x4 a_next = a_cur;
+                if (ct + 1 < CT) a_next = read_a(wcur, ct + 1, ks);
+                else if (ks + 1 < KS) a_next = read_a(wcur, 0, ks + 1);
+                if (ct == CT / 2) {
+                    if (ks + 1 < KS) read_b(b_next, g, ks + 1);
+                    else if (g + 1 < NST) read_b(b_next, g + 1, 0);     // next stage's slab is visible (same slice, or landed by tap 2)
+                }
+#pragma unroll
+                for (int t = 0; t < NPT; ++t)
+                    acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a_cur), __builtin_bit_cast(h8, b_cur[t]),
+                                                                         acc[ct][t], 0, 0, 0);
+                a_cur = a_next;
+            }
+#pragma unroll
+            for (int t = 0; t < NPT; ++t) b_cur[t] = b_next[t];
+        }
+        // own pieces of W(g+1) landed?  Younger than them: only this wave's slab pieces, issued right after W(g+1) at tap 0
+        if (more && tap == 0) {
+            vmcnt_uniform<NXQ>(nx_mine);
+        } else TG_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    int mrow[NPT];
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) mrow[t] = m0 + (wpos * NPT + t) * 16 + j;
+    conv_epilogue_h<F, CT, NPT, EPI>(acc, mrow, M, wco * CT * 16, kq, out32, out16, res, par);
+}
+
+// act16 = half(relu(x * s + t)): hands the f32 stem output to the first fp16 conv
+__global__ __launch_bounds__(256) void k_act_half(const float* __restrict__ x, _Float16* __restrict__ out, const float* __restrict__ s,
+                                                  const float* __restrict__ t, size_t n4, int F) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        const int c = (int)((i * 4) % (size_t)F);
+        h4 u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float w = v[e] * s[c + e] + t[c + e]; u[e] = (_Float16)(w > 0.f ? w : 0.f); }
+        reinterpret_cast<h4*>(out)[i] = u;
+    }
+}
+
+// stage-ordered fp16 copy of one F->F conv: dst[(slice*9 + tap)][cout][KC] = half(w[tap][cout][slice*KC + c])
+__global__ __launch_bounds__(256) void k_restage_half(const float* __restrict__ w, _Float16* __restrict__ dst, int F, int KC) {
+    const size_t total = (size_t)9 * F * F;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % KC);
+        const size_t r = i / KC;
+        const int co = (int)(r % F);
+        const int st = (int)(r / F);
+        const int sl = st / 9, tap = st % 9;
+        dst[i] = (_Float16)w[((size_t)tap * F + co) * F + sl * KC + c];
+    }
+}
+
 // Self_Attention core (model.py:301-315) for one board per workgroup, after the fused q/k/v 1x1 projection:
 //   energy[i][j] = q_i . k_j ; attention = softmax_j(energy) ; out[:, j] = sum_i v[:, i] * attention[i][j]   (note: summed over
 //   the softmaxed ROW index i, exactly as torch.bmm(proj_value, attention) does)
@@ -693,6 +927,39 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
     hipLaunchKernelGGL((k_obs_to_rows<S>), dim3(g0), dim3(256), 0, st, obs, n->x0, rows, n->C);
     float* x = n->bufA; float* y = n->bufB;
     if constexpr (F == 128 || F == 256) {
+        if (n->prec == 1) {
+            // fp16 chain: trunk x/y stay f32 (residual stream), conv inputs act16/h16 are fp16, stem and heads run in f32
+            if ((long long)M * F * 2 >= (1ll << 31)) TG_FAIL(ctx, TG_ERR_ARG, "fp16 path: rows * P * F * 2 bytes must stay below 2 GiB per activation buffer");
+            constexpr int KC = 64, WCO = F / 128, WPOS = 4, NTH = 64 * WCO * WPOS;
+            const int grid_h = (M + 64 * WPOS - 1) / (64 * WPOS);
+            const size_t nb = n->blocks.size();
+            hipLaunchKernelGGL((k_conv3x3<S, 16, F, false, 0>), dim3(grid), dim3(256), 0, st, (const float*)n->x0, x,
+                               (const float*)nullptr, n->stem.w, n->stem.b, (const float*)nullptr, (const float*)nullptr, M);
+            if (nb) {
+                const size_t n4 = (size_t)M * F / 4;
+                int ga = (int)((n4 + 255) / 256); if (ga > 65535) ga = 65535;
+                hipLaunchKernelGGL(k_act_half, dim3(ga), dim3(256), 0, st, (const float*)x, n->act16, n->blocks[0].s1, n->blocks[0].t1, n4, F);
+            }
+            for (size_t i = 0; i < nb; ++i) {
+                const BlockW& b = n->blocks[i];
+                const bool last = i + 1 == nb;
+                const float* sn = last ? nullptr : n->blocks[i + 1].s1;
+                const float* tn = last ? nullptr : n->blocks[i + 1].t1;
+                { ProfScope ps(n, st, conv_flops);
+                  hipLaunchKernelGGL((k_conv3x3_h<S, F, 0, KC, WCO, WPOS>), dim3(grid_h), dim3(NTH), 0, st, (const _Float16*)n->act16,
+                                     (float*)nullptr, n->h16, (const float*)nullptr, b.h1, b.c1.b, (const float*)nullptr, (const float*)nullptr, M); }
+                { ProfScope ps(n, st, conv_flops);
+                  hipLaunchKernelGGL((k_conv3x3_h<S, F, 1, KC, WCO, WPOS>), dim3(grid_h), dim3(NTH), 0, st, (const _Float16*)n->h16,
+                                     y, last ? (_Float16*)nullptr : n->act16, (const float*)x, b.h2, b.c2.b, sn, tn, M); }
+                float* t = x; x = y; y = t;
+            }
+            hipLaunchKernelGGL((k_conv3x3<S, F, 16, true, 0>), dim3(grid), dim3(256), 0, st, (const float*)x, n->hc,
+                               (const float*)nullptr, n->head.w, n->head.b, n->s_end, n->t_end, M);
+            hipLaunchKernelGGL((k_heads<S>), dim3(rows), dim3(256), 0, st, (const float*)n->hc, (const float*)n->hc, n->w_vo, n->b_vo,
+                               n->w_v, n->b_v, n->w_o, n->b_o, n->w_a, n->b_a, policy, value, own);
+            TG_HIP(ctx, hipGetLastError());
+            return TG_OK;
+        }
         if (n->dma && (long long)M * F * 4 < (1ll << 31)) {
             // prologue-free chain: every producer also writes relu(bn_next(.)) for its consumer
             constexpr int DNPT = TG_DMA_NPT;
@@ -854,15 +1121,19 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
     if (rows_cap <= 0) rows_cap = e->rows_cap > 0 ? e->rows_cap : 256;
     if (e->rows_cap > rows_cap) rows_cap = e->rows_cap;
     Net* n = e->net;
-    if (n && (n->rows_cap < rows_cap || n->arch != arch)) { tg_net_destroy(ctx); n = nullptr; }
+    const int prec = ctx->cfg.net_precision;
+    if (prec != 0 && prec != 1) TG_FAIL(ctx, TG_ERR_ARG, "net_precision: 0 (f32) or 1 (fp16 storage, f32 accumulate)");
+    if (n && (n->rows_cap < rows_cap || n->arch != arch || n->prec != prec)) { tg_net_destroy(ctx); n = nullptr; }
     const size_t P = (size_t)S * S, A = P + 1, Wq = (size_t)F / 4 * 2 + F;
     const bool any_att = pol || trunk.find('A') != std::string::npos;
     int NB = 0; for (char c : trunk) NB += c == 'R';
+    if (prec == 1 && (any_att || (F != 128 && F != 256)))
+        TG_FAIL(ctx, TG_ERR_ARG, "net_precision 1 (fp16) is built for attention-free towers with 128 or 256 filters");
     if (!n) {
         n = new Net();
         e->net = n;
         n->S = S; n->P = (int)P; n->A = (int)A; n->C = C; n->F = F; n->NB = NB; n->rows_cap = rows_cap; n->arch = arch; n->pol_att = pol;
-        n->blob_floats = n_floats;
+        n->blob_floats = n_floats; n->prec = prec;
         TG_HIP(ctx, hipMalloc((void**)&n->blob, sizeof(float) * n_floats));
         const size_t act = sizeof(float) * (size_t)rows_cap * P * F;
         TG_HIP(ctx, hipMalloc((void**)&n->bufA, act));
@@ -871,13 +1142,21 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
         TG_HIP(ctx, hipMalloc((void**)&n->x0, sizeof(float) * (size_t)rows_cap * P * 16));
         TG_HIP(ctx, hipMalloc((void**)&n->hc, sizeof(float) * (size_t)rows_cap * P * 16));
         TG_HIP(ctx, hipMalloc((void**)&n->own, sizeof(float) * (size_t)rows_cap * P));
-        TG_HIP(ctx, hipMalloc((void**)&n->frag, sizeof(float) * (size_t)(NB > 0 ? 2 * NB : 1) * 9 * F * F));
-        TG_HIP(ctx, hipMalloc((void**)&n->wstage, sizeof(float) * (size_t)(NB > 0 ? 2 * NB : 1) * 9 * F * F));
+
         if (any_att) TG_HIP(ctx, hipMalloc((void**)&n->bufQ, sizeof(float) * (size_t)rows_cap * P * Wq));
         if (pol) TG_HIP(ctx, hipMalloc((void**)&n->hca, sizeof(float) * (size_t)rows_cap * P * 16));
         n->dma = (!any_att && (F == 128 || F == 256)) ? (getenv("TG_DMA_CONV") ? atoi(getenv("TG_DMA_CONV")) : 2) : 0;
         if (F == 256 && n->dma == 1) n->dma = 2;    // the wave-private variant exists for F = 128 only   // 2 = k_conv3x3_sd (default), 1 = k_conv3x3_dma, 0 = k_conv3x3
+        if (prec == 1) n->dma = 0;
+        const size_t wcopy = (size_t)(NB > 0 ? 2 * NB : 1) * 9 * F * F;
+        if (n->dma == 1) TG_HIP(ctx, hipMalloc((void**)&n->frag, sizeof(float) * wcopy));
+        if (n->dma == 2) TG_HIP(ctx, hipMalloc((void**)&n->wstage, sizeof(float) * wcopy));
         if (n->dma) TG_HIP(ctx, hipMalloc((void**)&n->bufAct, act));
+        if (prec == 1) {
+            TG_HIP(ctx, hipMalloc((void**)&n->wh, sizeof(_Float16) * wcopy));
+            TG_HIP(ctx, hipMalloc((void**)&n->act16, act / 2));
+            TG_HIP(ctx, hipMalloc((void**)&n->h16, act / 2));
+        }
         const float* p = n->blob;
         auto take = [&](size_t k) { const float* q = p; p += k; return q; };
         auto take_att = [&](AttW& a) { a.qkv.w = take(Wq * F); a.qkv.b = take(Wq); a.gamma = take(1); a.s = take(F); a.t = take(F); };
@@ -891,7 +1170,7 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
                 b.s1 = take(F); b.t1 = take(F);
                 b.c1.w = take(9 * (size_t)F * F); b.c1.b = take(F);
                 b.c2.w = take(9 * (size_t)F * F); b.c2.b = take(F);
-                b.f1 = b.f2 = b.g1 = b.g2 = nullptr;
+                b.f1 = b.f2 = b.g1 = b.g2 = nullptr; b.h1 = b.h2 = nullptr;
             } else {
                 take_att(L.a);
             }
@@ -915,12 +1194,22 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
     }
     // weight refresh (trainer.py:76-79 -> self_play.py:913) is just this copy
     TG_HIP(ctx, hipMemcpyAsync(n->blob, blob, sizeof(float) * n_floats, hipMemcpyHostToDevice, ctx->stream));
-    // fragment-ordered copies of the F->F conv weights for k_conv3x3_dma:
-    //   frag f = group*NFRAG + ((slice*9 + tap)*NSUB + sub)*CTW + ct ; element [f][lane][e] = W[tap][ct*16 + (lane&15)][slice*CC + sub*16 + (lane>>4)*4 + e]
-    {
-        const size_t per = 9 * (size_t)F * F;
+    const size_t per = 9 * (size_t)F * F;
+    if (n->prec == 1) {
+        // stage-ordered fp16 copies, converted on the device from the blob just uploaded (round to nearest even)
+        for (size_t i = 0; i < n->blocks.size(); ++i) {
+            BlockW& b = n->blocks[i];
+            _Float16* d1 = n->wh + (2 * i) * per; _Float16* d2 = n->wh + (2 * i + 1) * per;
+            hipLaunchKernelGGL(k_restage_half, dim3(1024), dim3(256), 0, ctx->stream, b.c1.w, d1, F, 64);
+            hipLaunchKernelGGL(k_restage_half, dim3(1024), dim3(256), 0, ctx->stream, b.c2.w, d2, F, 64);
+            b.h1 = d1; b.h2 = d2;
+        }
+        TG_HIP(ctx, hipGetLastError());
+    } else if (n->dma == 1) {
+        // fragment-ordered copies of the F->F conv weights for k_conv3x3_dma:
+        //   frag f = group*NFRAG + ((slice*9 + tap)*NSUB + sub)*CTW + ct ; element [f][lane][e] = W[tap][ct*16 + (lane&15)][slice*CC + sub*16 + (lane>>4)*4 + e]
         const int CT = F / 16;
-        std::vector<float> fr(per * (n->blocks.empty() ? 1 : 2 * n->blocks.size()));
+        std::vector<float> fr(per * 2 * n->blocks.size());
         auto repack = [&](const float* w, float* dst) {
             constexpr int WCC = TG_WP_CC, NSUB = WCC / 16;
             const int CTW = CT < TG_WP_CTW ? CT : TG_WP_CTW, NG = CT / CTW;
@@ -937,8 +1226,17 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
                                             w[((size_t)tap * F + (cg * CTW + ct) * 16 + (lane & 15)) * F + sl * WCC + sub * 16 + (lane >> 4) * 4 + e];
                             }
         };
+        for (size_t i = 0; i < n->blocks.size(); ++i) {
+            BlockW& b = n->blocks[i];
+            repack(blob + (b.c1.w - n->blob), fr.data() + (2 * i) * per);
+            repack(blob + (b.c2.w - n->blob), fr.data() + (2 * i + 1) * per);
+            b.f1 = n->frag + (2 * i) * per; b.f2 = n->frag + (2 * i + 1) * per;
+        }
+        if (!fr.empty()) TG_HIP(ctx, hipMemcpyAsync(n->frag, fr.data(), sizeof(float) * fr.size(), hipMemcpyHostToDevice, ctx->stream));
+        TG_HIP(ctx, hipStreamSynchronize(ctx->stream));           // fr is a local
+    } else if (n->dma == 2) {
         // stage-ordered copy for k_conv3x3_sd: [slice*9 + tap][cout][16 channels of the slice]
-        std::vector<float> sg(fr.size());
+        std::vector<float> sg(per * 2 * n->blocks.size());
         auto restage = [&](const float* w, float* dst) {
             for (int sl = 0; sl < F / 16; ++sl)
                 for (int tap = 0; tap < 9; ++tap)
@@ -948,26 +1246,21 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
         };
         for (size_t i = 0; i < n->blocks.size(); ++i) {
             BlockW& b = n->blocks[i];
-            repack(blob + (b.c1.w - n->blob), fr.data() + (2 * i) * per);
-            repack(blob + (b.c2.w - n->blob), fr.data() + (2 * i + 1) * per);
             restage(blob + (b.c1.w - n->blob), sg.data() + (2 * i) * per);
             restage(blob + (b.c2.w - n->blob), sg.data() + (2 * i + 1) * per);
-            b.f1 = n->frag + (2 * i) * per; b.f2 = n->frag + (2 * i + 1) * per;
             b.g1 = n->wstage + (2 * i) * per; b.g2 = n->wstage + (2 * i + 1) * per;
         }
-        if (!n->blocks.empty()) {
-            TG_HIP(ctx, hipMemcpyAsync(n->frag, fr.data(), sizeof(float) * fr.size(), hipMemcpyHostToDevice, ctx->stream));
-            TG_HIP(ctx, hipMemcpyAsync(n->wstage, sg.data(), sizeof(float) * sg.size(), hipMemcpyHostToDevice, ctx->stream));
-        }
-        TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (!sg.empty()) TG_HIP(ctx, hipMemcpyAsync(n->wstage, sg.data(), sizeof(float) * sg.size(), hipMemcpyHostToDevice, ctx->stream));
+        TG_HIP(ctx, hipStreamSynchronize(ctx->stream));           // sg is a local
     }
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return TG_OK;
 }
 
 void tg_net_destroy(tg_ctx* ctx) {
     if (!ctx || !ctx->eng || !ctx->eng->net) return;
     Net* n = ctx->eng->net;
-    void* ptrs[] = {n->blob, n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->frag, n->bufQ, n->hca, n->bufAct, n->wstage};
+    void* ptrs[] = {n->blob, n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->frag, n->bufQ, n->hca, n->bufAct, n->wstage, n->wh, n->act16, n->h16};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t ev : n->ev) (void)hipEventDestroy(ev);
     delete n;

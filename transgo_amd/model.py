@@ -136,13 +136,20 @@ def load_into(ctx, sd, board_size, encode_dim, filters, blocks=None, rows_cap=0,
     ctx.call("tg_net_load_arch", arch.code.encode(), blob.ctypes.data_as(ctypes.c_void_p), blob.size, rows_cap)
 
 
+# tg_config.net_precision: "f16" = fp16 weights/activations in HBM and LDS with f32 accumulation and an f32 residual stream
+# (BASELINE config 5); attention-free towers with 128 or 256 filters only -- anything else is refused by tg_net_load.
+PRECISIONS = {"f32": 0, "f16": 1}
+
+
 class HipNetwork:
     """TransGoNetwork surface (model.py:11-27) for inference: main_prediction(x) -> (policy, value, own) as NumPy."""
 
-    def __init__(self, board_size=9, encode_dim=10, filters=128, blocks=6, rows_cap=1024, device=0, arch=None):
+    def __init__(self, board_size=9, encode_dim=10, filters=128, blocks=6, rows_cap=1024, device=0, arch=None,
+                 precision="f32"):
         cfg = _lib.default_config()
         cfg.board_size, cfg.encode_dim, cfg.net_filters, cfg.net_blocks, cfg.n_games, cfg.device = \
             board_size, encode_dim, filters, blocks, 0, device
+        cfg.net_precision = PRECISIONS[precision]
         self.ctx = _lib.Context(cfg)
         self.S, self.C, self.F, self.NB, self.rows_cap = board_size, encode_dim, filters, blocks, rows_cap
         self.arch = arch or tower_arch(blocks)

@@ -80,7 +80,8 @@ class BatchedSelfPlay:
             parallel_readouts=config.parallel_readouts, c_puct1=config.c_puct1, c_puct2=config.c_puct2,
             wu_loss=config.wu_loss, komi=config.komi, max_step=config.max_step,
             encode_dim=config.encode_state_channels, net_blocks=self.blocks, net_filters=self.filters,
-            arena_slots=arena_slots, device=device, evaluator=evaluator)
+            arena_slots=arena_slots, device=device, evaluator=evaluator,
+            net_precision=getattr(config, "inference_dtype", "f32"))
         self.keep_obs = keep_obs
         self.seed_fn = seed_fn
         self.games_started = np.zeros(n_games, np.int64)
@@ -210,7 +211,8 @@ class SelfPlay:
         mk = lambda: SelfPlayEngine(
             half, board_size=cfg.board_size, num_simulation=cfg.num_simulation, parallel_readouts=cfg.parallel_readouts,
             c_puct1=cfg.c_puct1, c_puct2=cfg.c_puct2, wu_loss=cfg.wu_loss, komi=cfg.komi, max_step=cfg.max_step,
-            encode_dim=cfg.encode_state_channels, net_blocks=w.blocks, net_filters=w.filters, device=w.device)
+            encode_dim=cfg.encode_state_channels, net_blocks=w.blocks, net_filters=w.filters, device=w.device,
+            net_precision=getattr(cfg, "inference_dtype", "f32"))
         eng = {"train": mk(), "eval": mk()}
         _model.load_into(eng["train"].ctx, _get(_call(shared_storage_worker.get_info, "weights")), cfg.board_size,
                          cfg.encode_state_channels, w.filters, arch=arch)

@@ -73,6 +73,15 @@ def cpu_baseline(budget_s=12.0, sims=400, F=128, N=6):
                       f"CPU 1 thread each), 9x9, {sims} sims/move, {N}x{F} tower, leaf batch 4; {sum(r[2] for r in res)} moves"}
 
 
+def kernel_name(S, filters, dtype):
+    """The F->F 3x3 conv kernel net.hip dispatches for this configuration (transgo_amd/csrc/net.hip: forward_t)."""
+    if dtype == "f16":
+        return f"k_conv3x3_h2<{S},{filters}> (fp16 operands, v_mfma_f32_16x16x32_f16, f32 accumulate, LDS-DMA fed)"
+    if filters in (128, 256) and os.environ.get("TG_DMA_CONV", "2") == "2":
+        return f"k_conv3x3_sd<{S},{filters}> (fp32 MFMA 16x16x4 implicit GEMM, LDS-DMA fed)"
+    return f"k_conv3x3<{S},{filters},{filters}> (fp32 MFMA 16x16x4 implicit GEMM)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,10 +186,9 @@ def main():
                        "step": "one move of every board (search + move selection + re-root + gather of finished games)"},
             "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(conv_tflops / peak, 4), "traffic": traffic,
-                         "traffic_note": "HBM bytes per full-batch launch, FETCH_SIZE x2 + WRITE_SIZE (profiles/r1_pmc_traffic.json)",
-                         "kernel": (f"k_conv3x3_sd<{S},128> (fp32 MFMA 16x16x4 implicit GEMM, LDS-DMA fed)" if a.filters == 128 and
-                                    os.environ.get("TG_DMA_CONV", "2") == "2" else
-                                    f"k_conv3x3<{S},{a.filters},{a.filters}> (fp32 MFMA 16x16x4 implicit GEMM)"),
+                         "traffic_note": ("HBM bytes per full-batch launch, FETCH_SIZE x2 + WRITE_SIZE (profiles/r1_pmc_traffic.json)"
+                                          if traffic is not None else "PMC traffic was collected for the default f32 workload only"),
+                         "kernel": kernel_name(S, a.filters, a.dtype),
                          "launches": int(nl.value), "avg_launch_ms": round(ms.value / max(1, nl.value), 4)},
             "cpu_baseline": cpu,
             "extra": {"leaves_per_s": round(evals_all / dt, 1), "mean_depth": round(depth_all / max(1.0, sims_all), 3),

@@ -41,7 +41,7 @@ struct Net {
     float* bufQ = nullptr; float* hca = nullptr;   // q|k|v projections [rows][P][1.5F]; policy head conv output
     float* bufAct = nullptr;                       // pre-activated input of the next conv (DMA path)
     int prec = 0;                                  // cfg.net_precision: 0 = f32, 1 = fp16 storage + f32 accumulate (k_conv3x3_h)
-    _Float16* wh = nullptr; _Float16* act16 = nullptr; _Float16* h16 = nullptr;   // fp16 path: weights [2*NB][F/64*9][F][64], activations [rows][P][F]
+    _Float16* wh = nullptr; _Float16* act16 = nullptr; _Float16* h16 = nullptr;   // fp16 path: weights [2*NB][F/32*9][F][32], activations [rows][P][F]
     int dma = 0;                                   // attention-free F=128 tower: 2 = k_conv3x3_sd (default), 1 = k_conv3x3_dma, 0 = k_conv3x3
     ConvW head; const float* w_vo = nullptr; const float* b_vo = nullptr; const float* w_v = nullptr; const float* b_v = nullptr;
     const float* w_o = nullptr; const float* b_o = nullptr; const float* w_a = nullptr; const float* b_a = nullptr;
@@ -406,6 +406,14 @@ __global__ __launch_bounds__(128, 2) void k_conv3x3_dma(const float* __restrict_
     conv_epilogue<F, CT, NPT, EPI>(acc, mrow, M, 0, kq, out, res, out2, par);
 }
 
+// XOR swizzle of the 16-B chunk index for LDS images with 64-byte rows read as MFMA fragments by ds_read_b128 (lane = (j, kq):
+// row base + j, chunk kq).  The instruction is served in four 16-lane groups, each holding all 16 values of j with kq = q0 for
+// j in {0-3, 12-15} and q0^1 for j in {4-11} (MI355X_MICROARCH.md, LDS table); the 16-B slot of a lane is (row%4)*4 + chunk, so the
+// four rows of one residue class, which use chunks (q0, q0^1, q0^1, q0) in row order, must land on four distinct chunks for every
+// alignment of the base row: chunk ^ 2*((row>>2)&1) does that ({c, c^3, c^1, c^2}), the obvious chunk ^ ((row>>2)&3) is 2-way
+// conflicted on every read (measured: SQ_LDS_BANK_CONFLICT = 49 % of SQ_LDS_IDX_ACTIVE).
+__device__ __forceinline__ int swz64(int row) { return ((row >> 2) & 1) << 1; }
+
 #ifdef TG_SD_STAMP
 __device__ unsigned long long tg_sd_dbg[8];          // diagnostic build only: summed cycles per phase, all waves
 #define TG_STAMP(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory")
@@ -418,8 +426,8 @@ __device__ unsigned long long tg_sd_dbg[8];          // diagnostic build only: s
 // Stage g = (16-channel slice, tap): its 8-KB weight tile arrives by global_load_lds from a stage-ordered copy of the weights
 // ([slice*9+tap][cout][16]) into a 3-deep LDS ring, two stages ahead of use; the activation slab of the NEXT slice arrives by
 // buffer_load..lds (bounds check = zero fill) into the other of two slab buffers while taps 5-8 of the current one run.
-// The LDS image is XOR-swizzled at the SOURCE (a 64-B row keeps chunk c at position c ^ ((row>>2)&3); DMA destinations must
-// stay lane-linear), so the 16 rows of a ds_read_b128 fragment fall on 16 distinct 16-B slots.  One raw s_barrier per stage,
+// The LDS image is XOR-swizzled at the SOURCE (a 64-B row keeps chunk c at position c ^ swz64(row); DMA destinations must
+// stay lane-linear); see swz64 for why that XOR makes every ds_read_b128 fragment read conflict-free.  One raw s_barrier per stage,
 // preceded by a counted vmcnt wait for the wave's own pieces of the next stage (DMAs retire in issue order).
 template <int S, int F, int EPI>
 __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sd(const float* __restrict__ in, float* __restrict__ out,
@@ -447,7 +455,7 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sd(const fl
     for (int i = tid; i < F; i += 256) { par[i] = bias[i]; par[F + i] = out2 ? s2[i] : 0.f; par[2 * F + i] = out2 ? t2[i] : 0.f; }
 
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, M * F * 4, 0x00020000);
-    const int prow = lane >> 2, pchunk = (lane & 3) ^ (lane >> 4);      // row within a 16-row piece, swizzled source chunk
+    const int prow = lane >> 2, pchunk = (lane & 3) ^ swz64(lane >> 2);      // row within a 16-row piece, swizzled source chunk
     auto dma_x = [&](int sl, int buf) {
 #pragma unroll
         for (int i = 0; i < NXQ; ++i) {
@@ -485,7 +493,7 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sd(const fl
         }
         vmask[t] = mk; vrow[t] = (wave * NPT + t) * 16 + j + HALO;
     }
-    const int aoff = j * CC + ((kq ^ ((j >> 2) & 3)) << 2);             // A fragment: row ct*16+j of the stage tile
+    const int aoff = j * CC + ((kq ^ swz64(j)) << 2);             // A fragment: row ct*16+j of the stage tile
     auto read_b = [&](f32x4* b, int g) {
         const int sl = g / 9, tap = g % 9;
         const int toff = (tap / 3 - 1) * S + (tap % 3 - 1);
@@ -493,7 +501,7 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sd(const fl
 #pragma unroll
         for (int t = 0; t < NPT; ++t) {
             const int R = vrow[t] + toff;
-            const float* src = ((vmask[t] >> tap) & 1) ? base + R * CC + ((kq ^ ((R >> 2) & 3)) << 2) : zrow + kq * 4;
+            const float* src = ((vmask[t] >> tap) & 1) ? base + R * CC + ((kq ^ swz64(R)) << 2) : zrow + kq * 4;
             b[t] = *reinterpret_cast<const f32x4*>(src);
         }
     };
@@ -573,14 +581,22 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sd(const fl
 
 // ---- fp16-storage 3x3 conv (BASELINE config 5: "fp16 policy/value inference"; f32 accumulate) ---------------------------------
 // Activations and weights are _Float16 in HBM and LDS, products accumulate in f32 on v_mfma_f32_16x16x32_f16 (16x the f32 MFMA
-// rate), so the kernel is shaped by what feeds the pipe rather than by the pipe: a workgroup computes 64*WPOS rows x ALL F
-// couts (at F=256: 8 waves = 2 cout halves x 4 position quarters, wave tile 128 couts x 64 rows = 8x4 accumulator tiles), which
-// makes the weight stream from L2 1.18 MB per 256 rows (~4 TB/s chip-wide at 1 PFLOP/s) and the LDS operand reads 12 b128 per
-// 32 MFMAs (~37 % of the LDS array).  Stage g = (KC-channel slice, tap): its F x KC weight tile arrives by global_load_lds into
-// a 2-deep ring one stage ahead; the slab of the next slice (rows + halo, KC channels) arrives during taps 0-1 of the current
-// one.  Rows are KC halfs (128 B at KC=64) with 16-B chunk c of row r stored at c ^ ((r / RP) % NCHK) (RP = rows per 256 B), the
-// XOR applied at the DMA source; a fragment read is lane (j, kq) -> row j, chunk 4*kstep + kq, the operand layout of the MFMA.
+// rate), so the kernel is shaped by what feeds the pipe rather than by the pipe; see k_conv3x3_h2 below.
 // EPI 0: out16 = half(relu(acc + bias))     EPI 1: out32 = acc + bias + res ; out16 = half(relu(out32 * s2 + t2)) (optional)
+// EPI 2: as EPI 1 with the residual already inside acc (k_conv3x3_h2 starts its accumulators from it)
+#ifndef TG_H_DA
+#define TG_H_DA 4
+#endif
+#ifdef TG_H_NT
+#define TG_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#define TG_NT_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define TG_NT_STORE(v, p) (*(p) = (v))          // measured: nontemporal stores/loads here are 7 % SLOWER (0.88 vs 0.82 ms per launch)
+#define TG_NT_LOAD(p) (*(p))
+#endif
+#ifndef TG_H2_GRID
+#define TG_H2_GRID 512       // multiple of 16
+#endif
 using h8 = __attribute__((ext_vector_type(8))) _Float16;
 using h4 = __attribute__((ext_vector_type(4))) _Float16;
 
@@ -594,7 +610,8 @@ __device__ __forceinline__ void vmcnt_uniform(int n) {
 template <int F, int CT, int NPT, int EPI>
 __device__ __forceinline__ void conv_epilogue_h(f32x4 (&acc)[CT][NPT], const int (&mrow)[NPT], int M, int co_base, int kq,
                                                 float* __restrict__ out32, _Float16* __restrict__ out16,
-                                                const float* __restrict__ res, const float* par) {
+                                                const float* __restrict__ res, const float* par, int pstride) {
+    // par: bias | s2 | t2 of THIS workgroup's couts (co_base .. ), sections pstride floats apart
     constexpr int CH = 4, NCH = (CT / CH) * NPT;
     static_assert(CT % CH == 0, "chunking");
     f32x4 r[2][CH];
@@ -603,7 +620,7 @@ __device__ __forceinline__ void conv_epilogue_h(f32x4 (&acc)[CT][NPT], const int
         if (mrow[t] < M) {
 #pragma unroll
             for (int i = 0; i < CH; ++i)
-                dst[i] = *reinterpret_cast<const f32x4*>(res + (size_t)mrow[t] * F + co_base + (h * CH + i) * 16 + kq * 4);
+                dst[i] = TG_NT_LOAD(reinterpret_cast<const f32x4*>(res + (size_t)mrow[t] * F + co_base + (h * CH + i) * 16 + kq * 4));
         }
     };
     if (EPI == 1) load_res(0, r[0]);
@@ -614,22 +631,22 @@ __device__ __forceinline__ void conv_epilogue_h(f32x4 (&acc)[CT][NPT], const int
         if (mrow[t] < M) {
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
-                const int col = co_base + (h * CH + i) * 16 + kq * 4;
-                f32x4 v = acc[h * CH + i][t] + *reinterpret_cast<const f32x4*>(par + col);
+                const int lc = (h * CH + i) * 16 + kq * 4, col = co_base + lc;
+                f32x4 v = acc[h * CH + i][t] + *reinterpret_cast<const f32x4*>(par + lc);
                 h4 u;
                 if (EPI == 0) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) u[e] = (_Float16)(v[e] > 0.f ? v[e] : 0.f);
-                    *reinterpret_cast<h4*>(out16 + (size_t)mrow[t] * F + col) = u;
+                    TG_NT_STORE(u, reinterpret_cast<h4*>(out16 + (size_t)mrow[t] * F + col));
                 } else {
-                    v = v + r[c & 1][i];
-                    *reinterpret_cast<f32x4*>(out32 + (size_t)mrow[t] * F + col) = v;
+                    if (EPI == 1) v = v + r[c & 1][i];
+                    TG_NT_STORE(v, reinterpret_cast<f32x4*>(out32 + (size_t)mrow[t] * F + col));
                     if (out16) {
-                        const f32x4 sc = *reinterpret_cast<const f32x4*>(par + F + col);
-                        const f32x4 sh = *reinterpret_cast<const f32x4*>(par + 2 * F + col);
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(par + pstride + lc);
+                        const f32x4 sh = *reinterpret_cast<const f32x4*>(par + 2 * pstride + lc);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { const float w = v[e] * sc[e] + sh[e]; u[e] = (_Float16)(w > 0.f ? w : 0.f); }
-                        *reinterpret_cast<h4*>(out16 + (size_t)mrow[t] * F + col) = u;
+                        TG_NT_STORE(u, reinterpret_cast<h4*>(out16 + (size_t)mrow[t] * F + col));
                     }
                 }
             }
@@ -637,47 +654,63 @@ __device__ __forceinline__ void conv_epilogue_h(f32x4 (&acc)[CT][NPT], const int
     }
 }
 
-template <int S, int F, int EPI, int KC, int WCO, int WPOS>
-__global__ __launch_bounds__(64 * WCO * WPOS, 1) void k_conv3x3_h(const _Float16* __restrict__ in, float* __restrict__ out32,
-                                                                  _Float16* __restrict__ out16, const float* __restrict__ res,
-                                                                  const _Float16* __restrict__ Ws, const float* __restrict__ bias,
-                                                                  const float* __restrict__ s2, const float* __restrict__ t2, int M) {
-    constexpr int P = S * S, HALO = S + 1, NW = WCO * WPOS, NT = 64 * NW, NPT = 4, TM = 64 * WPOS, CT = F / 16 / WCO;
-    constexpr int NCHK = KC / 8;                      // 16-B chunks per row
-    constexpr int RP = 16 / NCHK;                     // rows per 256 B of LDS
-    constexpr int RPP = 64 / NCHK;                    // rows per 1-KB DMA piece
-    constexpr int NSL = F / KC, NST = NSL * 9, KS = KC / 32;
+// Workgroup = 4 waves = 256 rows x 128 couts (the block index picks the cout half at F=256; wave tile 128 couts x 64 rows = 8x4
+// accumulator tiles, 12 ds_read_b128 per 32 MFMAs).  Stage = (32-channel slice, tap); stages are handled in PAIRS per barrier:
+// 4-slot weight ring (8 KB per slot, global_load_lds one pair ahead), two 32-channel slab buffers (rows + halo, buffer_load..lds,
+// bounds check = zero fill) -- 70 KB of LDS and <= 256 VGPRs, so TWO workgroups share a CU and one computes while the other sits
+// in its barrier, its slab wait or its epilogue.  The kernel is persistent (512 workgroups walk the (row tile, cout half) list):
+// the next tile's first DMAs are issued before the current tile's stores.  Weight traffic: 1.18 MB per 256 rows (~4 TB/s of L2
+// reads chip-wide at 1 PFLOP/s).  Measured shares of a 0.88-ms launch (8192 boards, F=256; ablation builds): MFMA loop alone
+// 0.44, DMA issue + traffic 0.17, epilogue 0.22, B-fragment addressing + reads 0.09, barriers 0.03, A reads 0.03.
+// An 8-wave 256x256 tile with one workgroup per CU (64-channel stages) measured 827 vs 888 TFLOP/s for this shape.
+template <int S, int F, int EPI>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restrict__ in, float* __restrict__ out32,
+                                                       _Float16* __restrict__ out16, const float* __restrict__ res,
+                                                       const _Float16* __restrict__ Ws, const float* __restrict__ bias,
+                                                       const float* __restrict__ s2, const float* __restrict__ t2, int M, int nblk) {
+    constexpr int P = S * S, HALO = S + 1, KC = 32, NW = 4, NPT = 4, TM = 64 * NW, NCO = 128, CT = NCO / 16, COS = F / NCO;
+    constexpr int NCHK = KC / 8, RP = 16 / NCHK, RPP = 64 / NCHK;       // 4 chunks per 64-B row, 4 rows per 256 B, 16 rows per piece
+    constexpr int NSL = F / KC, NST = NSL * 9, NPAIR = NST / 2, NSLOT = 4;
     constexpr int NROW = TM + 2 * HALO;
-    constexpr int NXP = (NROW + RPP - 1) / RPP;       // DMA pieces per slab
-    constexpr int NXQ = (NXP + NW - 1) / NW;          // ... issued by waves 0..NW-2
-    constexpr int NWP = F / RPP, WPW = NWP / NW;      // weight pieces per stage / per wave
-    static_assert(KC == 32 || KC == 64, "row = 64 or 128 bytes");
-    static_assert(NXQ <= 16 && NWP % NW == 0 && F % KC == 0 && CT % 4 == 0, "tile geometry");
+    constexpr int NXP = (NROW + RPP - 1) / RPP;
+    constexpr int NXQ = (NXP + NW - 1) / NW;
+    constexpr int WPW = NCO / RPP / NW;                                 // weight pieces per wave per stage (2)
+    static_assert(NST % 2 == 0 && F % NCO == 0 && NCO % (RPP * NW) == 0, "tile geometry");
     __shared__ __attribute__((aligned(16))) _Float16 xs[2][NXP * RPP * KC];
-    __shared__ __attribute__((aligned(16))) _Float16 ws[2][F * KC];
-    __shared__ __attribute__((aligned(16))) float par[3 * F];
+    __shared__ __attribute__((aligned(16))) _Float16 ws[NSLOT][NCO * KC];
+    __shared__ __attribute__((aligned(16))) float par[3 * NCO];
     __shared__ __attribute__((aligned(16))) float zrow[4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wco = wave / WPOS, wpos = wave % WPOS;
-    const int nx_mine = NXP - wave * NXQ < 0 ? 0 : NXP - wave * NXQ > NXQ ? NXQ : NXP - wave * NXQ;   // this wave's slab pieces
     const int j = lane & 15, kq = lane >> 4;
-    const int m0 = blockIdx.x * TM;
+    // the COS cout parts of one row tile are blocks b and b+8: same XCD (b % 8), dispatched together, so the slab's second read hits L2
+    // Persistent: this workgroup takes blocks bid, bid + gridDim.x, ... (gridDim.x is a multiple of 8*COS, so the cout part co0
+    // never changes); blocks whose rows lie past M (the block count is rounded up) are skipped.
+    auto tile_m0 = [&](int b) { return (COS == 1 ? b : (b / (8 * COS)) * 8 + b % 8) * TM; };
+    int bid = blockIdx.x;
+    const int co0 = COS == 1 ? 0 : ((bid / 8) % COS) * NCO;
+    while (bid < nblk && tile_m0(bid) >= M) bid += gridDim.x;
+    if (bid >= nblk) return;
+    int m0 = tile_m0(bid);
     if (tid < 4) zrow[tid] = 0.f;
-    for (int i = tid; i < F; i += NT) { par[i] = bias[i]; par[F + i] = out16 && s2 ? s2[i] : 0.f; par[2 * F + i] = out16 && t2 ? t2[i] : 0.f; }
-
+    for (int i = tid; i < NCO; i += 256) {
+        par[i] = bias[co0 + i]; par[NCO + i] = out16 && s2 ? s2[co0 + i] : 0.f; par[2 * NCO + i] = out16 && t2 ? t2[co0 + i] : 0.f;
+    }
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in), 0, M * F * 2, 0x00020000);
+    // a piece is 16 rows x 64 B: lane -> row prow, physical chunk pchk, which holds logical chunk pchk ^ swz64(row); pieces start at
+    // multiples of 16 rows, so the lane's share of every source address is ONE register (the rest is wave-uniform)
     const int prow = lane / NCHK, pchk = lane % NCHK;
-    auto dma_x = [&](int sl, int buf) {
+    const int lane_x = (prow * F + (pchk ^ swz64(prow)) * 8) * 2;         // bytes, activation rows are F halfs apart
+    const int lane_w = prow * KC + (pchk ^ swz64(prow)) * 8;              // halfs, stage-tile rows are KC halfs apart
+    auto dma_x = [&](int sl) {
 #pragma unroll
         for (int i = 0; i < NXQ; ++i) {
             const int q = wave * NXQ + i;
             if (q < NXP) {                                               // wave-uniform
-                const int r = q * RPP + prow;
-                if (r < NROW) {
-                    const int lc = pchk ^ ((r / RP) % NCHK);             // logical chunk stored at physical position pchk
-                    const int voff = ((m0 - HALO + r) * F + sl * KC + lc * 8) * 2;       // outside the tensor: reads 0
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (tg_lds_void*)(&xs[buf][q * 512]), 16, voff, 0, 0, 0);
+                if (q * RPP + prow < NROW) {
+                    // the whole offset must travel in voffset: soffset is not range-checked, and rows outside the tensor must read 0
+                    const int voff = ((m0 - HALO + q * RPP) * F + sl * KC) * 2 + lane_x;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (tg_lds_void*)(&xs[sl & 1][q * 512]), 16, voff, 0, 0, 0);
                 }
             }
         }
@@ -686,94 +719,153 @@ __global__ __launch_bounds__(64 * WCO * WPOS, 1) void k_conv3x3_h(const _Float16
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
             const int pc = wave * WPW + i;
-            const int r = pc * RPP + prow;
-            const int lc = pchk ^ ((r / RP) % NCHK);
-            __builtin_amdgcn_global_load_lds(Ws + ((size_t)g * F + r) * KC + lc * 8, (tg_lds_void*)(&ws[g & 1][pc * 512]), 16, 0, 0);
+            const _Float16* wb = Ws + ((size_t)g * F + co0 + pc * RPP) * KC;                       // wave-uniform
+            __builtin_amdgcn_global_load_lds(wb + lane_w, (tg_lds_void*)(&ws[g % NSLOT][pc * 512]), 16, 0, 0);
         }
     };
-    unsigned vmask[NPT]; int vrow[NPT];
-#pragma unroll
-    for (int t = 0; t < NPT; ++t) {
-        const int m = m0 + (wpos * NPT + t) * 16 + j;
-        unsigned mk = 0;
-        if (m < M) {
-            const int p = m % P, x = p % S, y = p / S;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-                if (yy >= 0 && yy < S && xx >= 0 && xx < S) mk |= 1u << tap;
-            }
-        }
-        vmask[t] = mk; vrow[t] = (wpos * NPT + t) * 16 + j + HALO;
-    }
-    const int arow = wco * CT * 16 + j;                                  // A fragment: cout row of tile ct = arow + ct*16
-    const int asw = (j / RP) % NCHK;
-    auto read_a = [&](const _Float16* wcur, int ct, int ks) {
-        return *reinterpret_cast<const f32x4*>(wcur + (arow + ct * 16) * KC + (((ks * 4 + kq) ^ asw) << 3));
+    auto prologue = [&]() {                                              // order matters for the counted wait below
+        dma_x(0); dma_w(0); dma_w(1);
+        if (NSL > 1) dma_x(1);
+        dma_w(2); dma_w(3);
     };
-    auto read_b = [&](f32x4* b, int g, int ks) {
-        const int sl = g / 9, tap = g % 9;
-        const int toff = (tap / 3 - 1) * S + (tap % 3 - 1);
-        const _Float16* base = xs[sl & 1];
+    prologue();
+    bool first = true;
+    const int aoff = j * KC + ((kq ^ swz64(j)) << 3);                    // A fragment of cout tile ct: + ct*16*KC
+    for (;;) {
+        unsigned vmask[NPT]; int vrow[NPT];
 #pragma unroll
         for (int t = 0; t < NPT; ++t) {
-            const int R = vrow[t] + toff;
-            const _Float16* src = ((vmask[t] >> tap) & 1) ? base + R * KC + (((ks * 4 + kq) ^ ((R / RP) % NCHK)) << 3)
-                                                          : reinterpret_cast<const _Float16*>(zrow);
-            b[t] = *reinterpret_cast<const f32x4*>(src);
+            const int m = m0 + (wave * NPT + t) * 16 + j;
+            unsigned mk = 0;
+            if (m < M) {
+                const int p = m % P, x = p % S, y = p / S;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                    if (yy >= 0 && yy < S && xx >= 0 && xx < S) mk |= 1u << tap;
+                }
+            }
+            vmask[t] = mk; vrow[t] = (wave * NPT + t) * 16 + j + HALO;
         }
-    };
-    f32x4 acc[CT][NPT];
+        auto read_b = [&](f32x4* b, int g) {
+            const int sl = g / 9, tap = g % 9;
+            const int toff = (tap / 3 - 1) * S + (tap % 3 - 1);
+            const _Float16* base = xs[sl & 1];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+            for (int t = 0; t < NPT; ++t) {
+                const int R = vrow[t] + toff;
+                const _Float16* src = ((vmask[t] >> tap) & 1) ? base + R * KC + ((kq ^ swz64(R)) << 3)
+                                                              : reinterpret_cast<const _Float16*>(zrow);
+                b[t] = *reinterpret_cast<const f32x4*>(src);
+            }
+        };
+        // EPI 1: the accumulators START from the residual (32 loads per wave that fly while the first DMAs land), so the epilogue
+        // has no load in it -- a load issued after stores waits for them (one in-order counter): 8 serial round trips per tile
+        f32x4 acc[CT][NPT];
 #pragma unroll
-        for (int t = 0; t < NPT; ++t) acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    dma_x(0, 0); dma_w(0);
-    TG_VMCNT(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    f32x4 b_cur[NPT], b_next[NPT];
-    read_b(b_cur, 0, 0);
-
-    for (int g = 0; g < NST; ++g) {
-        const _Float16* wcur = ws[g & 1];
-        const int tap = g % 9;
-        const bool more = g / 9 + 1 < NSL;
-        // slot (g+1)&1 held stage g-1, and slab buffer (slice+1)&1 the previous slice: every wave left them before the last barrier
-        if (g + 1 < NST) dma_w(g + 1);
-        if (more && tap == 0) dma_x(g / 9 + 1, (g / 9 + 1) & 1);
-        f32x4 a_cur = read_a(wcur, 0, 0);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        for (int t = 0; t < NPT; ++t) {
+            const int m = m0 + (wave * NPT + t) * 16 + j;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                f32x4 a_next = a_cur;
-                if (ct + 1 < CT) a_next = read_a(wcur, ct + 1, ks);
-                else if (ks + 1 < KS) a_next = read_a(wcur, 0, ks + 1);
-                if (ct == CT / 2) {
-                    if (ks + 1 < KS) read_b(b_next, g, ks + 1);
-                    else if (g + 1 < NST) read_b(b_next, g + 1, 0);     // next stage's slab is visible (same slice, or landed by tap 2)
+                acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (EPI == 1 && m < M) acc[ct][t] = *reinterpret_cast<const f32x4*>(res + (size_t)m * F + co0 + ct * 16 + kq * 4);
+            }
+        }
+#ifdef TG_SD_STAMP
+        unsigned long long t_start, t_pro, t_0, t_a, t_b, t_c, t_loop, t_end, s_dma = 0, s_bar = 0, s_iss = 0, s_cmp = 0;
+        TG_STAMP(t_start);
+#endif
+        // first tile of a residual-free launch: only the prologue DMAs are in flight, so the wait can leave X(1), W(2), W(3) out;
+        // otherwise residual loads / the previous tile's stores are younger than them and everything is waited for
+        if (EPI != 1 && first && NSL > 1) vmcnt_uniform<NXQ + 2 * WPW>((NXP - wave * NXQ < 0 ? 0 : NXP - wave * NXQ > NXQ ? NXQ : NXP - wave * NXQ) + 2 * WPW);
+        else if (EPI != 1 && first) TG_VMCNT(2 * WPW);
+        else TG_VMCNT(0);
+        first = false;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#ifdef TG_SD_STAMP
+        TG_STAMP(t_pro);
+#endif
+        f32x4 b_cur[NPT], b_next[NPT];
+        read_b(b_cur, 0);
+
+#pragma unroll 1                                                         // unrolled, hipcc keeps 4 pairs of address state live and spills
+        for (int pp = 0; pp < NPAIR; ++pp) {
+            constexpr int NU = 2 * CT, DA = TG_H_DA;
+            const int g0 = 2 * pp;
+#ifdef TG_SD_STAMP
+            TG_STAMP(t_0);
+#endif
+            // A fragments run DA-1 steps ahead of their MFMAs (a step = 4 MFMAs = 64 cycles; an LDS read under load takes longer)
+            f32x4 a[DA];
+#pragma unroll
+            for (int u = 0; u < DA - 1; ++u) a[u] = *reinterpret_cast<const f32x4*>(ws[(g0 + u / CT) % NSLOT] + (u % CT) * 16 * KC + aoff);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                if (u + DA - 1 < NU) {
+                    const int un = u + DA - 1;
+                    a[un % DA] = *reinterpret_cast<const f32x4*>(ws[(g0 + un / CT) % NSLOT] + (un % CT) * 16 * KC + aoff);
                 }
+                if (u % CT == CT / 2 && g0 + u / CT + 1 < NST) read_b(b_next, g0 + u / CT + 1);   // that stage's slab is visible (see below)
 #pragma unroll
                 for (int t = 0; t < NPT; ++t)
-                    acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a_cur), __builtin_bit_cast(h8, b_cur[t]),
-                                                                         acc[ct][t], 0, 0, 0);
-                a_cur = a_next;
+                    acc[u % CT][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a[u % DA]), __builtin_bit_cast(h8, b_cur[t]),
+                                                                            acc[u % CT][t], 0, 0, 0);
+                if (u % CT == CT - 1) {
+#pragma unroll
+                    for (int t = 0; t < NPT; ++t) b_cur[t] = b_next[t];
+                }
+                __builtin_amdgcn_sched_barrier(0);                      // keep each step's reads where they were issued (hipcc sinks them to their use)
             }
-#pragma unroll
-            for (int t = 0; t < NPT; ++t) b_cur[t] = b_next[t];
+            // every DMA of this wave was issued at least one pair ago: wait for all of them, then meet the other waves.  After the
+            // barrier the two slots of this pair are free, and so is the slab buffer of slice sl-1 once stage 9*sl-1 is behind us.
+#ifdef TG_SD_STAMP
+            TG_STAMP(t_a);
+#endif
+            TG_VMCNT(0);
+#ifdef TG_SD_STAMP
+            TG_STAMP(t_b);
+#endif
+            __builtin_amdgcn_s_barrier();
+#ifdef TG_SD_STAMP
+            TG_STAMP(t_c);
+            s_cmp += t_a - t_0; s_dma += t_b - t_a; s_bar += t_c - t_b;
+#endif
+            const int gdone = g0 + 1;                                    // last finished stage
+            // the slab of slice sl+1 goes into the buffer slice sl-1 used: issue it right after the pair that finished stage 9*sl-1
+            // (it is fenced by the NEXT pair's barrier, i.e. before stage 9*sl+3; first read by the prefetch in stage 9*sl+8)
+            {
+                const int sl = (gdone + 1) / 9;
+                if (sl >= 1 && sl + 1 < NSL && (gdone == 9 * sl - 1 || gdone == 9 * sl)) dma_x(sl + 1);
+            }
+            if (g0 + 4 < NST) { dma_w(g0 + 4); dma_w(g0 + 5); }
+#ifdef TG_SD_STAMP
+            TG_STAMP(t_0); s_iss += t_0 - t_c;
+#endif
         }
-        // own pieces of W(g+1) landed?  Younger than them: only this wave's slab pieces, issued right after W(g+1) at tap 0
-        if (more && tap == 0) {
-            vmcnt_uniform<NXQ>(nx_mine);
-        } else TG_VMCNT(0);
-        __builtin_amdgcn_s_barrier();
-    }
-    int mrow[NPT];
+#ifdef TG_SD_STAMP
+        TG_STAMP(t_loop);
+#endif
+        int mrow[NPT];
 #pragma unroll
-    for (int t = 0; t < NPT; ++t) mrow[t] = m0 + (wpos * NPT + t) * 16 + j;
-    conv_epilogue_h<F, CT, NPT, EPI>(acc, mrow, M, wco * CT * 16, kq, out32, out16, res, par);
+        for (int t = 0; t < NPT; ++t) mrow[t] = m0 + (wave * NPT + t) * 16 + j;
+        // every wave is past the last barrier: ring and slab buffers are free, so the next tile's first loads go out before this
+        // tile's results do and land while the epilogue runs
+        int nb = bid + gridDim.x;
+        while (nb < nblk && tile_m0(nb) >= M) nb += gridDim.x;
+        const bool have_next = nb < nblk;
+        if (have_next) { bid = nb; m0 = tile_m0(nb); prologue(); }
+        conv_epilogue_h<F, CT, NPT, (EPI == 1 ? 2 : EPI)>(acc, mrow, M, co0, kq, out32, out16, res, par, NCO);
+#ifdef TG_SD_STAMP
+        TG_STAMP(t_end);
+        if (lane == 0) {
+            atomicAdd(&tg_sd_dbg[0], t_pro - t_start); atomicAdd(&tg_sd_dbg[1], s_dma); atomicAdd(&tg_sd_dbg[2], s_bar);
+            atomicAdd(&tg_sd_dbg[3], t_loop - t_pro); atomicAdd(&tg_sd_dbg[4], t_end - t_loop); atomicAdd(&tg_sd_dbg[5], 1ull);
+            atomicAdd(&tg_sd_dbg[6], s_iss); atomicAdd(&tg_sd_dbg[7], s_cmp);
+        }
+#endif
+        if (!have_next) break;
+    }
 }
 
 // act16 = half(relu(x * s + t)): hands the f32 stem output to the first fp16 conv
@@ -930,8 +1022,10 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
         if (n->prec == 1) {
             // fp16 chain: trunk x/y stay f32 (residual stream), conv inputs act16/h16 are fp16, stem and heads run in f32
             if ((long long)M * F * 2 >= (1ll << 31)) TG_FAIL(ctx, TG_ERR_ARG, "fp16 path: rows * P * F * 2 bytes must stay below 2 GiB per activation buffer");
-            constexpr int KC = 64, WCO = F / 128, WPOS = 4, NTH = 64 * WCO * WPOS;
-            const int grid_h = (M + 64 * WPOS - 1) / (64 * WPOS);
+            const int grid_h = (M + 255) / 256;                                      // 256-row tiles
+            constexpr int COS = F / 128;
+            const int nblk_h2 = COS == 1 ? grid_h : (grid_h + 7) / 8 * 8 * COS;      // (row tile, cout part) blocks
+            const int grid_h2 = nblk_h2 < TG_H2_GRID ? nblk_h2 : TG_H2_GRID;       // persistent: 2 workgroups per CU x 256 CUs
             const size_t nb = n->blocks.size();
             hipLaunchKernelGGL((k_conv3x3<S, 16, F, false, 0>), dim3(grid), dim3(256), 0, st, (const float*)n->x0, x,
                                (const float*)nullptr, n->stem.w, n->stem.b, (const float*)nullptr, (const float*)nullptr, M);
@@ -945,12 +1039,13 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                 const bool last = i + 1 == nb;
                 const float* sn = last ? nullptr : n->blocks[i + 1].s1;
                 const float* tn = last ? nullptr : n->blocks[i + 1].t1;
+                _Float16* const a16 = last ? (_Float16*)nullptr : n->act16;
                 { ProfScope ps(n, st, conv_flops);
-                  hipLaunchKernelGGL((k_conv3x3_h<S, F, 0, KC, WCO, WPOS>), dim3(grid_h), dim3(NTH), 0, st, (const _Float16*)n->act16,
-                                     (float*)nullptr, n->h16, (const float*)nullptr, b.h1, b.c1.b, (const float*)nullptr, (const float*)nullptr, M); }
+                  hipLaunchKernelGGL((k_conv3x3_h2<S, F, 0>), dim3(grid_h2), dim3(256), 0, st, (const _Float16*)n->act16,
+                                     (float*)nullptr, n->h16, (const float*)nullptr, b.h1, b.c1.b, (const float*)nullptr, (const float*)nullptr, M, nblk_h2); }
                 { ProfScope ps(n, st, conv_flops);
-                  hipLaunchKernelGGL((k_conv3x3_h<S, F, 1, KC, WCO, WPOS>), dim3(grid_h), dim3(NTH), 0, st, (const _Float16*)n->h16,
-                                     y, last ? (_Float16*)nullptr : n->act16, (const float*)x, b.h2, b.c2.b, sn, tn, M); }
+                  hipLaunchKernelGGL((k_conv3x3_h2<S, F, 1>), dim3(grid_h2), dim3(256), 0, st, (const _Float16*)n->h16,
+                                     y, a16, (const float*)x, b.h2, b.c2.b, sn, tn, M, nblk_h2); }
                 float* t = x; x = y; y = t;
             }
             hipLaunchKernelGGL((k_conv3x3<S, F, 16, true, 0>), dim3(grid), dim3(256), 0, st, (const float*)x, n->hc,
@@ -1200,8 +1295,8 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
         for (size_t i = 0; i < n->blocks.size(); ++i) {
             BlockW& b = n->blocks[i];
             _Float16* d1 = n->wh + (2 * i) * per; _Float16* d2 = n->wh + (2 * i + 1) * per;
-            hipLaunchKernelGGL(k_restage_half, dim3(1024), dim3(256), 0, ctx->stream, b.c1.w, d1, F, 64);
-            hipLaunchKernelGGL(k_restage_half, dim3(1024), dim3(256), 0, ctx->stream, b.c2.w, d2, F, 64);
+            hipLaunchKernelGGL(k_restage_half, dim3(1024), dim3(256), 0, ctx->stream, b.c1.w, d1, F, 32);     // k_conv3x3_h2: 32-channel stages
+            hipLaunchKernelGGL(k_restage_half, dim3(1024), dim3(256), 0, ctx->stream, b.c2.w, d2, F, 32);
             b.h1 = d1; b.h2 = d2;
         }
         TG_HIP(ctx, hipGetLastError());

@@ -2,7 +2,6 @@
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["TG_DMA_CONV"] = "2"
 from transgo_amd.model import HipNetwork, random_weights
 from transgo_amd import _lib
 B = 16384

@@ -26,15 +26,14 @@ using namespace tg;
 namespace tg {
 
 struct ConvW { const float* w; const float* b; };
-struct BlockW { const float* s1; const float* t1; ConvW c1; ConvW c2; const float* f1; const float* f2; const float* g1; const float* g2;
-                const _Float16* h1; const _Float16* h2; };   // f1/f2: fragment-ordered, g1/g2: stage-ordered f32, h1/h2: stage-ordered fp16 copies
+struct BlockW { const float* s1; const float* t1; ConvW c1; ConvW c2; const float* g1; const float* g2;
+                const _Float16* h1; const _Float16* h2; };   // g1/g2: stage-ordered f32, h1/h2: stage-ordered fp16 copies of c1.w / c2.w
 struct AttW { ConvW qkv; const float* gamma; const float* s; const float* t; };      // Self_Attention, model.py:288-315
 struct Layer { int kind; int ridx; AttW a; };                                         // kind 0: residual block blocks[ridx]; 1: attention
 
 struct Net {
     int F = 0, NB = 0, C = 0, S = 0, P = 0, A = 0;
     float* blob = nullptr; size_t blob_floats = 0;
-    float* frag = nullptr;   // [2*NB][...] fragment-ordered F->F conv weights (k_conv3x3_dma)
     float* wstage = nullptr; // [2*NB][F/16*9][F][16] stage-ordered F->F conv weights (k_conv3x3_sd)
     ConvW stem; std::vector<BlockW> blocks; std::vector<Layer> layers; const float* s_end = nullptr; const float* t_end = nullptr;
     bool pol_att = false; AttW patt; ConvW head_a; std::string arch;
@@ -42,7 +41,7 @@ struct Net {
     float* bufAct = nullptr;                       // pre-activated input of the next conv (DMA path)
     int prec = 0;                                  // cfg.net_precision: 0 = f32, 1 = fp16 storage + f32 accumulate (k_conv3x3_h)
     _Float16* wh = nullptr; _Float16* act16 = nullptr; _Float16* h16 = nullptr;   // fp16 path: weights [2*NB][F/32*9][F][32], activations [rows][P][F]
-    int dma = 0;                                   // attention-free F=128 tower: 2 = k_conv3x3_sd (default), 1 = k_conv3x3_dma, 0 = k_conv3x3
+    int dma = 0;                                   // attention-free F=128/256 f32 tower: 1 = k_conv3x3_sd chain (default), 0 = k_conv3x3 (TG_DMA_CONV=0)
     ConvW head; const float* w_vo = nullptr; const float* b_vo = nullptr; const float* w_v = nullptr; const float* b_v = nullptr;
     const float* w_o = nullptr; const float* b_o = nullptr; const float* w_a = nullptr; const float* b_a = nullptr;
     float* x0 = nullptr;   // [rows][P][16] input planes, channel-minor
@@ -59,17 +58,10 @@ struct Net {
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using h8 = __attribute__((ext_vector_type(8))) _Float16;
+using h4 = __attribute__((ext_vector_type(4))) _Float16;
 __device__ __forceinline__ int tid0() { return (int)threadIdx.x; }
 
-#ifndef TG_DMA_NPT
-#define TG_DMA_NPT 4
-#endif
-#ifndef TG_WP_CTW
-#define TG_WP_CTW 8          // cout tiles (of 16) per fragment group of the fragment-ordered weight copy (k_conv3x3_dma: all 8 of F=128)
-#endif
-#ifndef TG_WP_CC
-#define TG_WP_CC 16          // input channels per activation slice of k_conv3x3_dma
-#endif
 
 
 template <int S>
@@ -90,8 +82,8 @@ __global__ __launch_bounds__(256) void k_obs_to_rows(const float* __restrict__ o
 // Loads and stores retire through ONE in-order counter (vmcnt), so a load issued after stores waits for all of them: per-cout
 // parameters therefore come from LDS (par = bias | s2 | t2, COUT floats each), and the residual is fetched one 4-tile chunk
 // ahead of the stores of the previous chunk, which turns ~CT*NPT serialized memory round trips into counted, overlapped ones.
-// EPI 0: relu(acc + bias)   EPI 1: acc + bias + res   EPI 2: acc + bias;   out2 (optional) = relu(v * s2 + t2).
-template <int COUT, int CT, int NPT, int EPI>
+// EPI 0: relu(acc + bias)   EPI 1: acc + bias + res   EPI 2: acc + bias;   out2 (optional) = relu(v * s2 + t2), stored as fp16 if H2.
+template <int COUT, int CT, int NPT, int EPI, bool H2 = false>
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[CT][NPT], const int (&mrow)[NPT], int M, int co_base, int kq,
                                               float* __restrict__ out, const float* __restrict__ res, float* __restrict__ out2,
                                               const float* par) {
@@ -131,6 +123,12 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[CT][NPT], const int (
                     f32x4 u;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { float w = v[e] * sc[e] + sh[e]; u[e] = w > 0.f ? w : 0.f; }
+                    if (H2) {                                            // out2 is an fp16 tensor (first conv input of the fp16 chain)
+                        h4 uh;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) uh[e] = (_Float16)u[e];
+                        *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(out2) + (size_t)mrow[t] * COUT + co_base + col) = uh;
+                    } else
                     *reinterpret_cast<f32x4*>(out2 + (size_t)mrow[t] * COUT + co_base + col) = u;
                 }
             }
@@ -140,7 +138,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[CT][NPT], const int (
 
 // EPI 0: out = relu(acc + bias)      EPI 1: out = acc + bias + res      EPI 2: out = acc + bias
 // NTAP 9: 3x3 convolution with zero padding; NTAP 1: 1x1 convolution (the q/k/v projections of Self_Attention, model.py:294-296)
-template <int S, int CIN, int COUT, bool PRO, int EPI, int NTAP = 9, int NPT = 2>
+template <int S, int CIN, int COUT, bool PRO, int EPI, int NTAP = 9, int NPT = 2, bool H2 = false>
 // NPT = 3 only pays with two waves per SIMD (<= 256 registers, a handful of spills): measured 132 vs 118 TFLOP/s at one
 __global__ __launch_bounds__(256, (NPT > 2 ? 2 : 1)) void k_conv3x3(const float* __restrict__ in, float* __restrict__ out,
                                                  const float* __restrict__ res, const float* __restrict__ Wt,
@@ -157,7 +155,11 @@ __global__ __launch_bounds__(256, (NPT > 2 ? 2 : 1)) void k_conv3x3(const float*
     __shared__ float xs[NROW * RS];
     __shared__ __attribute__((aligned(16))) float par[3 * COUT];            // bias | s2 | t2 for the epilogue
     for (int i = tid0(); i < COUT; i += 256) { par[i] = bias[i]; par[COUT + i] = out2 ? s2[i] : 0.f; par[2 * COUT + i] = out2 ? t2[i] : 0.f; }
-    __shared__ float ws[COUT * RS];
+    // WALL: a narrow output (the 16-wide head conv) is latency-bound, not MFMA-bound -- stage all NTAP weight tiles of a channel
+    // slice at once (2 barriers per slice instead of 2 per tap; 480 -> ~ us per forward at 16384 leaves)
+    constexpr bool WALL = COUT <= 16 && NTAP == 9;
+    constexpr int WT = WALL ? NTAP : 1;             // weight tiles resident in LDS
+    __shared__ float ws[WT * COUT * RS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int j = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.x * TM;
@@ -187,14 +189,14 @@ __global__ __launch_bounds__(256, (NPT > 2 ? 2 : 1)) void k_conv3x3(const float*
     // Software pipeline: the global loads of stage s+1 (one tap's weights; every 9th stage also the next 32-channel
     // slice of the activation tile) are issued before the MFMA block of stage s and land in registers while it runs;
     // they are written to LDS after the barrier that ends it.
-    constexpr int WL = (COUT * C4 + 255) / 256;
+    constexpr int WL = (WT * COUT * C4 + 255) / 256;
     constexpr int XL = (NROW * C4 + 255) / 256;
     f32x4 wreg[WL], xreg[XL];
     auto load_w = [&](int cc, int tap) {
 #pragma unroll
         for (int i = 0; i < WL; ++i) {
             const int idx = tid + i * 256;
-            if (idx < COUT * C4) {
+            if (idx < WT * COUT * C4) {                                   // WALL: idx also runs over the taps (tap argument = 0)
                 const int co = idx / C4, c4 = idx % C4;
                 wreg[i] = *reinterpret_cast<const f32x4*>(Wt + ((size_t)tap * COUT + co) * CIN + cc + c4 * 4);
             }
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256, (NPT > 2 ? 2 : 1)) void k_conv3x3(const float*
 #pragma unroll
         for (int i = 0; i < WL; ++i) {
             const int idx = tid + i * 256;
-            if (idx < COUT * C4) { const int co = idx / C4, c4 = idx % C4; *reinterpret_cast<f32x4*>(&ws[co * RS + c4 * 4]) = wreg[i]; }
+            if (idx < WT * COUT * C4) { const int co = idx / C4, c4 = idx % C4; *reinterpret_cast<f32x4*>(&ws[co * RS + c4 * 4]) = wreg[i]; }
         }
     };
     auto load_x = [&](int cc) {
@@ -243,12 +245,14 @@ __global__ __launch_bounds__(256, (NPT > 2 ? 2 : 1)) void k_conv3x3(const float*
     load_w(0, 0);
     for (int cc = 0; cc < CIN; cc += CC) {
         for (int tap = 0; tap < NTAP; ++tap) {
-            __syncthreads();
-            if (tap == 0) store_x(cc);
-            store_w();
-            __syncthreads();
-            if (tap < NTAP - 1) load_w(cc, tap + 1);
-            else if (cc + CC < CIN) { load_w(cc + CC, 0); load_x(cc + CC); }
+            if (!WALL || tap == 0) {
+                __syncthreads();
+                if (tap == 0) store_x(cc);
+                store_w();
+                __syncthreads();
+                if (!WALL && tap < NTAP - 1) load_w(cc, tap + 1);
+                else if (cc + CC < CIN) { load_w(cc + CC, 0); load_x(cc + CC); }
+            }
             const int toff = NTAP == 9 ? (tap / 3 - 1) * S + (tap % 3 - 1) : 0;
 #pragma unroll
             for (int sub = 0; sub < CC / 16; ++sub) {
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(256, (NPT > 2 ? 2 : 1)) void k_conv3x3(const float*
                 }
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(&ws[(ct * 16 + j) * RS + sub * 16 + kq * 4]);
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(&ws[((WALL ? tap * COUT : 0) + ct * 16 + j) * RS + sub * 16 + kq * 4]);
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -275,136 +279,12 @@ __global__ __launch_bounds__(256, (NPT > 2 ? 2 : 1)) void k_conv3x3(const float*
     int mrow[NPT];
 #pragma unroll
     for (int t = 0; t < NPT; ++t) mrow[t] = m0 + (wave * NPT + t) * 16 + j;
-    conv_epilogue<COUT, CT, NPT, EPI>(acc, mrow, M, 0, kq, out, res, out2, par);
+    conv_epilogue<COUT, CT, NPT, EPI, H2>(acc, mrow, M, 0, kq, out, res, out2, par);
 }
 
-// ---- ALTERNATIVE PATH (TG_DMA_CONV=1 in the environment; 129 TFLOP/s vs 134 for k_conv3x3_sd; parity-tested) ---------------
-// ---- LDS-DMA 3x3 conv for the F->F convs of an attention-free tower --------------------------------------------------------
-// Every wave is an independent worker (no workgroup barrier anywhere): 16*NPT consecutive rows x all F output channels,
-// NPT x F/16 accumulator tiles of v_mfma_f32_16x16x4_f32.  Nothing is staged through registers:
-//   * activations (already activated by the producer's epilogue): the wave's 16*NPT + 2*(S+1) rows, 16 channels at a time, land in
-//     one of two wave-private LDS slabs by `buffer_load ... lds`; rows outside the batch come back as zeros from the buffer
-//     bounds check, taps that leave the board read a dedicated zero row;
-//   * weights: a fragment-ordered copy ([slice][tap][cout tile][lane][4], built at load time) streams through an 8-deep
-//     wave-private LDS ring by `global_load_lds` (1 KB fully coalesced per fragment), 8 fragments = 128 MFMAs ahead of use;
-//   * every wait is a counted `s_waitcnt vmcnt(N)`: DMAs retire in issue order, the ring keeps 7 younger fragments in
-//     flight, plus the 6 slab pieces while the next slice is arriving (last tap of a slice).
+// LDS pointer type of the LDS-DMA builtins; counted wait on the in-order vector-memory counter (loads, stores and LDS-DMA share it)
 typedef __attribute__((address_space(3))) void tg_lds_void;
 #define TG_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
-
-template <int S, int F, int EPI, int NPT>
-__global__ __launch_bounds__(128, 2) void k_conv3x3_dma(const float* __restrict__ in, float* __restrict__ out,
-                                                        const float* __restrict__ res, const float* __restrict__ Wf,
-                                                        const float* __restrict__ bias, float* __restrict__ out2,
-                                                        const float* __restrict__ s2, const float* __restrict__ t2, int M) {
-    constexpr int P = S * S, HALO = S + 1, WT = 16 * NPT, CT = F / 16;
-    constexpr int CC = 16, NSL = F / CC;
-    constexpr int NROW = WT + 2 * HALO;               // rows per slab
-    constexpr int NX = (NROW + 15) / 16;              // DMA pieces per slab (16 rows x 64 B each)
-    constexpr int NR = 8;                             // ring depth = fragments per tap
-    static_assert(CT == NR, "one tap's fragments fill the ring exactly (F = 128)");
-    constexpr int NFRAG = NSL * 9 * CT;
-    constexpr int SLAB = NROW * CC;                   // floats
-    __shared__ __attribute__((aligned(16))) float lds[2][2 * SLAB + NR * 256 + 16];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int j = lane & 15, kq = lane >> 4;
-    const int m0 = (blockIdx.x * 2 + wave) * WT;
-    __shared__ __attribute__((aligned(16))) float par[3 * F];
-    for (int i = tid; i < F; i += 128) { par[i] = bias[i]; par[F + i] = out2 ? s2[i] : 0.f; par[2 * F + i] = out2 ? t2[i] : 0.f; }
-    __syncthreads();                                  // the only barrier: epilogue parameters (before any wave may leave)
-    if (m0 >= M) return;
-    float* slab = lds[wave];                          // [2][NROW][16]
-    float* ring = slab + 2 * SLAB;                    // [NR][64 lanes][4]
-    float* zrow = ring + NR * 256;                    // [16] zeros
-    if (lane < 4) *reinterpret_cast<f32x4*>(zrow + lane * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, M * F * 4, 0x00020000);
-    // piece q of slice sl: lane -> row 16q + lane/4, 16-byte chunk lane%4 (rows past NROW are skipped)
-    const int xrow = lane >> 2, xch = lane & 3;
-    auto dma_x = [&](int sl, int buf) {
-#pragma unroll
-        for (int q = 0; q < NX; ++q) {
-            const int r = q * 16 + xrow;
-            if (r < NROW) {
-                const int voff = ((m0 - HALO + r) * F + sl * CC + xch * 4) * 4;        // negative / past the end: reads back 0
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (tg_lds_void*)(slab + buf * SLAB + q * 256), 16, voff, 0, 0, 0);
-            }
-        }
-    };
-    const float* wf = Wf + lane * 4;
-    auto dma_w = [&](int f, int slot) {
-        f = f < NFRAG ? f : NFRAG - 1;
-        __builtin_amdgcn_global_load_lds(wf + (size_t)f * 256, (tg_lds_void*)(ring + slot * 256), 16, 0, 0);
-    };
-
-    int vrow[NPT]; unsigned vmask[NPT];
-#pragma unroll
-    for (int t = 0; t < NPT; ++t) {
-        const int m = m0 + t * 16 + j;
-        unsigned mk = 0;
-        if (m < M) {
-            const int p = m % P, x = p % S, y = p / S;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-                if (yy >= 0 && yy < S && xx >= 0 && xx < S) mk |= 1u << tap;
-            }
-        }
-        vmask[t] = mk; vrow[t] = (t * 16 + j + HALO) * CC;
-    }
-    f32x4 acc[CT][NPT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int t = 0; t < NPT; ++t) acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    dma_x(0, 0);
-#pragma unroll
-    for (int d = 0; d < NR; ++d) dma_w(d, d);
-    TG_VMCNT(NR - 1);                                 // slab 0 and fragment 0 have landed (NR-1 younger ring DMAs in flight)
-    f32x4 a_cur = *reinterpret_cast<const f32x4*>(ring + lane * 4);
-
-    // One fragment ahead: while the 16 MFMAs of fragment f run, fragment f+1 is already being read out of the ring, and
-    // slot f is refilled (fragment f+NR) as soon as they have issued.  Counted waits (DMAs retire in issue order):
-    // fragment f+1 is complete once at most NR-2 younger ring DMAs remain -- plus the NX slab pieces during the last tap of a
-    // slice for fragments that were issued before them.
-    int fbase = 0;
-    for (int sl = 0; sl < NSL; ++sl) {
-        const float* xs = slab + (sl & 1) * SLAB;
-        const bool more = sl + 1 < NSL;
-        for (int tap = 0; tap < 9; ++tap) {
-            const int toff = ((tap / 3 - 1) * S + (tap % 3 - 1)) * CC;
-            const bool prefetch_x = more && tap == 8;
-            if (prefetch_x) dma_x(sl + 1, (sl + 1) & 1);
-            f32x4 b[NPT];
-#pragma unroll
-            for (int t = 0; t < NPT; ++t) {
-                const float* src = ((vmask[t] >> tap) & 1) ? xs + vrow[t] + toff + kq * 4 : zrow + kq * 4;
-                b[t] = *reinterpret_cast<const f32x4*>(src);
-            }
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                if (prefetch_x && ct < CT - 1) TG_VMCNT(NR - 2 + NX); else TG_VMCNT(NR - 2);
-                const f32x4 a_next = *reinterpret_cast<const f32x4*>(ring + ((ct + 1) % NR) * 256 + lane * 4);
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                    for (int t = 0; t < NPT; ++t)
-                        acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s4], b[t][s4], acc[ct][t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                dma_w(fbase + ct + NR, ct);          // refill the slot whose fragment (a_cur) left the ring one step ago
-                __builtin_amdgcn_sched_barrier(0);
-                a_cur = a_next;
-            }
-            fbase += NR;
-        }
-    }
-    TG_VMCNT(0);                                      // no DMA may outlive the wave's LDS
-    int mrow[NPT];
-#pragma unroll
-    for (int t = 0; t < NPT; ++t) mrow[t] = m0 + t * 16 + j;
-    conv_epilogue<F, CT, NPT, EPI>(acc, mrow, M, 0, kq, out, res, out2, par);
-}
 
 // XOR swizzle of the 16-B chunk index for LDS images with 64-byte rows read as MFMA fragments by ds_read_b128 (lane = (j, kq):
 // row base + j, chunk kq).  The instruction is served in four 16-lane groups, each holding all 16 values of j with kq = q0 for
@@ -429,8 +309,15 @@ __device__ unsigned long long tg_sd_dbg[8];          // diagnostic build only: s
 // The LDS image is XOR-swizzled at the SOURCE (a 64-B row keeps chunk c at position c ^ swz64(row); DMA destinations must
 // stay lane-linear); see swz64 for why that XOR makes every ds_read_b128 fragment read conflict-free.  One raw s_barrier per stage,
 // preceded by a counted vmcnt wait for the wave's own pieces of the next stage (DMAs retire in issue order).
+// workgroups per CU of k_conv3x3_sd: three if its LDS (two slabs, 3-slot weight ring, epilogue parameters, zero row) fits three times
+constexpr int sd_wg_per_cu(int S, int F) {
+    const int npt = F == 128 ? 3 : 2, nrow = 64 * npt + 2 * (S + 1);
+    const int lds = (2 * nrow * 16 + 3 * F * 16 + 3 * F + 16) * 4;
+    return F == 128 && 3 * lds <= 160 * 1024 ? 3 : 2;
+}
+
 template <int S, int F, int EPI>
-__global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sd(const float* __restrict__ in, float* __restrict__ out,
+__global__ __launch_bounds__(256, sd_wg_per_cu(S, F)) void k_conv3x3_sd(const float* __restrict__ in, float* __restrict__ out,
                                                        const float* __restrict__ res, const float* __restrict__ Ws,
                                                        const float* __restrict__ bias, float* __restrict__ out2,
                                                        const float* __restrict__ s2, const float* __restrict__ t2, int M) {
@@ -597,9 +484,6 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sd(const fl
 #ifndef TG_H2_GRID
 #define TG_H2_GRID 512       // multiple of 16
 #endif
-using h8 = __attribute__((ext_vector_type(8))) _Float16;
-using h4 = __attribute__((ext_vector_type(4))) _Float16;
-
 // s_waitcnt vmcnt(n) for a wave-uniform n in [0, N]: the instruction takes an immediate
 template <int N>
 __device__ __forceinline__ void vmcnt_uniform(int n) {
@@ -669,7 +553,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
                                                        const _Float16* __restrict__ Ws, const float* __restrict__ bias,
                                                        const float* __restrict__ s2, const float* __restrict__ t2, int M, int nblk) {
     constexpr int P = S * S, HALO = S + 1, KC = 32, NW = 4, NPT = 4, TM = 64 * NW, NCO = 128, CT = NCO / 16, COS = F / NCO;
-    constexpr int NCHK = KC / 8, RP = 16 / NCHK, RPP = 64 / NCHK;       // 4 chunks per 64-B row, 4 rows per 256 B, 16 rows per piece
+    constexpr int NCHK = KC / 8, RPP = 64 / NCHK;                       // 4 chunks per 64-B row, 16 rows per 1-KB DMA piece
     constexpr int NSL = F / KC, NST = NSL * 9, NPAIR = NST / 2, NSLOT = 4;
     constexpr int NROW = TM + 2 * HALO;
     constexpr int NXP = (NROW + RPP - 1) / RPP;
@@ -868,19 +752,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
     }
 }
 
-// act16 = half(relu(x * s + t)): hands the f32 stem output to the first fp16 conv
-__global__ __launch_bounds__(256) void k_act_half(const float* __restrict__ x, _Float16* __restrict__ out, const float* __restrict__ s,
-                                                  const float* __restrict__ t, size_t n4, int F) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
-        const int c = (int)((i * 4) % (size_t)F);
-        h4 u;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const float w = v[e] * s[c + e] + t[c + e]; u[e] = (_Float16)(w > 0.f ? w : 0.f); }
-        reinterpret_cast<h4*>(out)[i] = u;
-    }
-}
-
 // stage-ordered fp16 copy of one F->F conv: dst[(slice*9 + tap)][cout][KC] = half(w[tap][cout][slice*KC + c])
 __global__ __launch_bounds__(256) void k_restage_half(const float* __restrict__ w, _Float16* __restrict__ dst, int F, int KC) {
     const size_t total = (size_t)9 * F * F;
@@ -1027,13 +898,10 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
             const int nblk_h2 = COS == 1 ? grid_h : (grid_h + 7) / 8 * 8 * COS;      // (row tile, cout part) blocks
             const int grid_h2 = nblk_h2 < TG_H2_GRID ? nblk_h2 : TG_H2_GRID;       // persistent: 2 workgroups per CU x 256 CUs
             const size_t nb = n->blocks.size();
-            hipLaunchKernelGGL((k_conv3x3<S, 16, F, false, 0>), dim3(grid), dim3(256), 0, st, (const float*)n->x0, x,
-                               (const float*)nullptr, n->stem.w, n->stem.b, (const float*)nullptr, (const float*)nullptr, M);
-            if (nb) {
-                const size_t n4 = (size_t)M * F / 4;
-                int ga = (int)((n4 + 255) / 256); if (ga > 65535) ga = 65535;
-                hipLaunchKernelGGL(k_act_half, dim3(ga), dim3(256), 0, st, (const float*)x, n->act16, n->blocks[0].s1, n->blocks[0].t1, n4, F);
-            }
+            // stem in f32; its epilogue also writes the first conv input relu(bn1(x)) as fp16
+            hipLaunchKernelGGL((k_conv3x3<S, 16, F, false, 0, 9, 2, true>), dim3(grid), dim3(256), 0, st, (const float*)n->x0, x,
+                               (const float*)nullptr, n->stem.w, n->stem.b, (const float*)nullptr, (const float*)nullptr, M,
+                               nb ? reinterpret_cast<float*>(n->act16) : (float*)nullptr, nb ? n->blocks[0].s1 : nullptr, nb ? n->blocks[0].t1 : nullptr);
             for (size_t i = 0; i < nb; ++i) {
                 const BlockW& b = n->blocks[i];
                 const bool last = i + 1 == nb;
@@ -1057,8 +925,6 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
         }
         if (n->dma && (long long)M * F * 4 < (1ll << 31)) {
             // prologue-free chain: every producer also writes relu(bn_next(.)) for its consumer
-            constexpr int DNPT = TG_DMA_NPT;
-            const int grid_d = ((M + 16 * DNPT - 1) / (16 * DNPT) + 1) / 2;
             const size_t nb = n->blocks.size();
             const float* s0 = nb ? n->blocks[0].s1 : n->s_end; const float* t0 = nb ? n->blocks[0].t1 : n->t_end;
             hipLaunchKernelGGL((k_conv3x3<S, 16, F, false, 0>), dim3(grid), dim3(256), 0, st, (const float*)n->x0, x,
@@ -1071,19 +937,11 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                 constexpr int SD_TM = F == 128 ? 192 : 128;
                 const int grid_sd = (M + SD_TM - 1) / SD_TM;
                 { ProfScope ps(n, st, conv_flops);
-                  if (n->dma == 2)
-                      hipLaunchKernelGGL((k_conv3x3_sd<S, F, 0>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufAct, n->bufH,
-                                         (const float*)nullptr, b.g1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M);
-                  else if constexpr (F == 128)
-                      hipLaunchKernelGGL((k_conv3x3_dma<S, F, 0, DNPT>), dim3(grid_d), dim3(128), 0, st, (const float*)n->bufAct, n->bufH,
-                                         (const float*)nullptr, b.f1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M); }
+                  hipLaunchKernelGGL((k_conv3x3_sd<S, F, 0>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufAct, n->bufH,
+                                     (const float*)nullptr, b.g1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M); }
                 { ProfScope ps(n, st, conv_flops);
-                  if (n->dma == 2)
-                      hipLaunchKernelGGL((k_conv3x3_sd<S, F, 1>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufH, y,
-                                         (const float*)x, b.g2, b.c2.b, n->bufAct, sn, tn, M);
-                  else if constexpr (F == 128)
-                      hipLaunchKernelGGL((k_conv3x3_dma<S, F, 1, DNPT>), dim3(grid_d), dim3(128), 0, st, (const float*)n->bufH, y,
-                                         (const float*)x, b.f2, b.c2.b, n->bufAct, sn, tn, M); }
+                  hipLaunchKernelGGL((k_conv3x3_sd<S, F, 1>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufH, y,
+                                     (const float*)x, b.g2, b.c2.b, n->bufAct, sn, tn, M); }
                 float* t = x; x = y; y = t;
             }
             hipLaunchKernelGGL((k_conv3x3<S, F, 16, false, 0>), dim3(grid), dim3(256), 0, st, (const float*)n->bufAct, n->hc,
@@ -1240,12 +1098,10 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
 
         if (any_att) TG_HIP(ctx, hipMalloc((void**)&n->bufQ, sizeof(float) * (size_t)rows_cap * P * Wq));
         if (pol) TG_HIP(ctx, hipMalloc((void**)&n->hca, sizeof(float) * (size_t)rows_cap * P * 16));
-        n->dma = (!any_att && (F == 128 || F == 256)) ? (getenv("TG_DMA_CONV") ? atoi(getenv("TG_DMA_CONV")) : 2) : 0;
-        if (F == 256 && n->dma == 1) n->dma = 2;    // the wave-private variant exists for F = 128 only   // 2 = k_conv3x3_sd (default), 1 = k_conv3x3_dma, 0 = k_conv3x3
+        n->dma = (!any_att && (F == 128 || F == 256)) ? (getenv("TG_DMA_CONV") ? (atoi(getenv("TG_DMA_CONV")) != 0) : 1) : 0;
         if (prec == 1) n->dma = 0;
         const size_t wcopy = (size_t)(NB > 0 ? 2 * NB : 1) * 9 * F * F;
-        if (n->dma == 1) TG_HIP(ctx, hipMalloc((void**)&n->frag, sizeof(float) * wcopy));
-        if (n->dma == 2) TG_HIP(ctx, hipMalloc((void**)&n->wstage, sizeof(float) * wcopy));
+        if (n->dma) TG_HIP(ctx, hipMalloc((void**)&n->wstage, sizeof(float) * wcopy));
         if (n->dma) TG_HIP(ctx, hipMalloc((void**)&n->bufAct, act));
         if (prec == 1) {
             TG_HIP(ctx, hipMalloc((void**)&n->wh, sizeof(_Float16) * wcopy));
@@ -1265,7 +1121,7 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
                 b.s1 = take(F); b.t1 = take(F);
                 b.c1.w = take(9 * (size_t)F * F); b.c1.b = take(F);
                 b.c2.w = take(9 * (size_t)F * F); b.c2.b = take(F);
-                b.f1 = b.f2 = b.g1 = b.g2 = nullptr; b.h1 = b.h2 = nullptr;
+                b.g1 = b.g2 = nullptr; b.h1 = b.h2 = nullptr;
             } else {
                 take_att(L.a);
             }
@@ -1300,36 +1156,7 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
             b.h1 = d1; b.h2 = d2;
         }
         TG_HIP(ctx, hipGetLastError());
-    } else if (n->dma == 1) {
-        // fragment-ordered copies of the F->F conv weights for k_conv3x3_dma:
-        //   frag f = group*NFRAG + ((slice*9 + tap)*NSUB + sub)*CTW + ct ; element [f][lane][e] = W[tap][ct*16 + (lane&15)][slice*CC + sub*16 + (lane>>4)*4 + e]
-        const int CT = F / 16;
-        std::vector<float> fr(per * 2 * n->blocks.size());
-        auto repack = [&](const float* w, float* dst) {
-            constexpr int WCC = TG_WP_CC, NSUB = WCC / 16;
-            const int CTW = CT < TG_WP_CTW ? CT : TG_WP_CTW, NG = CT / CTW;
-            const size_t nfrag = (size_t)(F / WCC) * 9 * NSUB * CTW;
-            for (int cg = 0; cg < NG; ++cg)
-                for (int sl = 0; sl < F / WCC; ++sl)
-                    for (int tap = 0; tap < 9; ++tap)
-                        for (int sub = 0; sub < NSUB; ++sub)
-                            for (int ct = 0; ct < CTW; ++ct) {
-                                const size_t f = cg * nfrag + ((size_t)(sl * 9 + tap) * NSUB + sub) * CTW + ct;
-                                for (int lane = 0; lane < 64; ++lane)
-                                    for (int e = 0; e < 4; ++e)
-                                        dst[(f * 64 + lane) * 4 + e] =
-                                            w[((size_t)tap * F + (cg * CTW + ct) * 16 + (lane & 15)) * F + sl * WCC + sub * 16 + (lane >> 4) * 4 + e];
-                            }
-        };
-        for (size_t i = 0; i < n->blocks.size(); ++i) {
-            BlockW& b = n->blocks[i];
-            repack(blob + (b.c1.w - n->blob), fr.data() + (2 * i) * per);
-            repack(blob + (b.c2.w - n->blob), fr.data() + (2 * i + 1) * per);
-            b.f1 = n->frag + (2 * i) * per; b.f2 = n->frag + (2 * i + 1) * per;
-        }
-        if (!fr.empty()) TG_HIP(ctx, hipMemcpyAsync(n->frag, fr.data(), sizeof(float) * fr.size(), hipMemcpyHostToDevice, ctx->stream));
-        TG_HIP(ctx, hipStreamSynchronize(ctx->stream));           // fr is a local
-    } else if (n->dma == 2) {
+    } else if (n->dma) {
         // stage-ordered copy for k_conv3x3_sd: [slice*9 + tap][cout][16 channels of the slice]
         std::vector<float> sg(per * 2 * n->blocks.size());
         auto restage = [&](const float* w, float* dst) {
@@ -1355,7 +1182,7 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
 void tg_net_destroy(tg_ctx* ctx) {
     if (!ctx || !ctx->eng || !ctx->eng->net) return;
     Net* n = ctx->eng->net;
-    void* ptrs[] = {n->blob, n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->frag, n->bufQ, n->hca, n->bufAct, n->wstage, n->wh, n->act16, n->h16};
+    void* ptrs[] = {n->blob, n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->bufQ, n->hca, n->bufAct, n->wstage, n->wh, n->act16, n->h16};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t ev : n->ev) (void)hipEventDestroy(ev);
     delete n;

@@ -73,6 +73,27 @@ def cpu_baseline(budget_s=12.0, sims=400, F=128, N=6):
                       f"CPU 1 thread each), 9x9, {sims} sims/move, {N}x{F} tower, leaf batch 4; {sum(r[2] for r in res)} moves"}
 
 
+def tree_roofline(S, C, sims, evals, depth_sum, children_scored, tree_ms, waves):
+    """Second regime of SURVEY.md 8(d): selection / leaf step / expansion / backup are scan-and-graph work priced in HBM bytes.
+    Algorithmic bytes per simulation with the mean depth d and mean fan-out a measured in this run (rank 0's games):
+    selection d*(a+1)*32 (one 32-B record per child scored + the parent) + path updates 2*(d+1)*16*2 (pending then backup, read
+    and write) + board state 2*state + legal mask 2*ceil(A/8) + feature planes written C*P*4 + policy/value read (A+1)*4 +
+    expansion a*32; time = HIP events around every k_collect and k_absorb launch."""
+    if sims <= 0 or tree_ms <= 0:
+        return None
+    P, A = S * S, S * S + 1
+    d = depth_sum / sims
+    a = children_scored / max(1.0, depth_sum)
+    state = 48 if S == 9 else 112
+    per_eval = C * P * 4 + (A + 1) * 4 + a * 32 + 2 * ((A + 7) // 8)
+    bytes_per_sim = d * (a + 1) * 32 + 2 * (d + 1) * 16 * 2 + 2 * state + per_eval * (evals / sims)
+    gbs = sims * bytes_per_sim / (tree_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 5),
+            "bytes_per_sim": round(bytes_per_sim, 1), "mean_depth": round(d, 3), "mean_fanout": round(a, 2),
+            "tree_ms_per_wave": round(tree_ms / max(1, waves), 4), "share_of_step": None,
+            "kernels": "k_collect + k_absorb (one 64-lane workgroup per game; latency/occupancy-bound, see DESIGN.md)"}
+
+
 def kernel_name(S, filters, dtype):
     """The F->F 3x3 conv kernel net.hip dispatches for this configuration (transgo_amd/csrc/net.hip: forward_t)."""
     if dtype == "f16":
@@ -144,6 +165,9 @@ def main():
         gathered += len(gather_records(fin, S, 10, 0, cdev))
     eng = sp.engine
     eng.ctx.call("tg_prof_enable", 1, 8192)
+    eng.ctx.call("tg_prof_enable_tree", 1, 8192)
+    cs0 = ctypes.c_uint64()
+    eng.ctx.call("tg_prof_read_tree", None, None, None, ctypes.byref(cs0))
     st0 = eng.stats()
     barrier()
     t0 = time.perf_counter()
@@ -155,6 +179,8 @@ def main():
     st1 = eng.stats()
     ms, nl, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
     eng.ctx.call("tg_prof_read", ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(fl))
+    cms, ams, nw, cs1 = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64(), ctypes.c_uint64()
+    eng.ctx.call("tg_prof_read_tree", ctypes.byref(cms), ctypes.byref(ams), ctypes.byref(nw), ctypes.byref(cs1))
 
     sims = st1["sims"] - st0["sims"]; evals = st1["evals"] - st0["evals"]; depth = st1["depth_sum"] - st0["depth_sum"]
     t = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -176,6 +202,9 @@ def main():
         conv_tflops = (fl.value / (ms.value * 1e-3)) / 1e12 if ms.value > 0 else 0.0
         fpl = flops_per_leaf(S, 10, a.filters, a.blocks)
         peak = PEAK_F16_MATRIX_TFLOPS if a.dtype == "f16" else PEAK_F32_MATRIX_TFLOPS
+        tree = tree_roofline(S, 10, sims, evals, depth, cs1.value - cs0.value, cms.value + ams.value, nw.value)
+        if tree:
+            tree["share_of_step"] = round((cms.value + ams.value) / (dt * 1e3), 4)
         line = {
             "metric": "MCTS simulations/sec", "value": round(value, 1), "unit": "sims/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
@@ -190,6 +219,7 @@ def main():
                                           if traffic is not None else "PMC traffic was collected for the default f32 workload only"),
                          "kernel": kernel_name(S, a.filters, a.dtype),
                          "launches": int(nl.value), "avg_launch_ms": round(ms.value / max(1, nl.value), 4)},
+            "roofline_tree": tree,
             "cpu_baseline": cpu,
             "extra": {"leaves_per_s": round(evals_all / dt, 1), "mean_depth": round(depth_all / max(1.0, sims_all), 3),
                       "net_tflops_end_to_end": round(evals_all * fpl / dt / 1e12, 2),

@@ -175,6 +175,11 @@ int tg_net_predict(tg_ctx* ctx, const float* obs, int n_rows, float* policy, flo
 /* HIP-event timing of the dominant kernel (3x3 conv F->F) on the launch stream: enable, run, read totals. */
 int tg_prof_enable(tg_ctx* ctx, int on, int max_launches);
 int tg_prof_read(tg_ctx* ctx, double* conv_ms, int64_t* conv_launches, double* conv_flops);
+/* The same for the tree stage (k_collect = selection + leaf step + pseudo-expansion + feature planes, self_play.py:607-650;
+ * k_absorb = complete_update + backup, :651-654, :727-764): event time per kind, number of waves, and the number of children
+ * scored by PUCT summed over all selection levels since the last reset (mean fan-out = children_scored / depth_sum). */
+int tg_prof_enable_tree(tg_ctx* ctx, int on, int max_waves);
+int tg_prof_read_tree(tg_ctx* ctx, double* collect_ms, double* absorb_ms, int64_t* waves, uint64_t* children_scored);
 
 /* ---- device-resident replay store + batch sampler (replaces replay_buffer.py:30-47 + the stacking of trainer.py:46-54) ----
  * Positions are stored once, un-augmented and compact; entry e of the reference's ring of augmented tuples is

@@ -67,6 +67,9 @@ SIGNATURES = {
     "tg_net_predict": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
     "tg_prof_enable": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "tg_prof_read": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]),
+    "tg_prof_enable_tree": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    "tg_prof_read_tree": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
+                                          ctypes.POINTER(ctypes.c_uint64)]),
     "tg_replay_create": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "tg_replay_destroy": (None, [_vp]),
     "tg_replay_append": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int]),

@@ -45,6 +45,9 @@ struct Engine {
     std::vector<double> h_noise;
     std::vector<int32_t> h_nchild;
     Net* net = nullptr;
+    // HIP-event timing of the tree stage (k_collect, k_absorb) on the engine's stream, switched by tg_prof_enable
+    bool tprof = false; std::vector<hipEvent_t> tev; size_t tev_used = 0; double collect_ms = 0, absorb_ms = 0; long tree_waves = 0;
+    std::vector<char> tev_kind;
 };
 
 }  // namespace tg

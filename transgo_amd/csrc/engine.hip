@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64) void k_collect(EngineDev d) {
     int* paths = d.path_nodes + (size_t)g * sc.R * sc.maxd;
     int npaths = 0, err = 0;
     int leafs[8], rows[8];
-    unsigned long long sims = 0, depth_sum = 0, evals = 0;
+    unsigned long long sims = 0, depth_sum = 0, evals = 0, child_sum = 0;
 
     for (int attempt = 0; attempt < 2 * sc.R && npaths < sc.R && !err; ++attempt) {    // self_play.py:616
         int* path = paths + npaths * sc.maxd;
@@ -194,6 +194,7 @@ __global__ __launch_bounds__(64) void k_collect(EngineDev d) {
         while (cur.flags & F_OPEN) {
             const int blk = cur.block;
             const int nchild = hdr_of<S>(arena, blk)->nchild;
+            child_sum += nchild;
             const double sq = sqrt((double)(cur.n + cur.pending));
             double scv[NPASS];
             double best = -INFINITY;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(64) void k_collect(EngineDev d) {
     }
     if (lane == 0) {
         c->n_paths = npaths; c->free_slot = free_slot; c->error |= err;
-        c->sims += sims; c->depth_sum += depth_sum; c->evals += evals; c->tie_draws += rng.draws;
+        c->sims += sims; c->depth_sum += depth_sum; c->evals += evals; c->tie_draws += rng.draws; c->child_sum += child_sum;
         d.rng[g].pos = rng.pos;
         if (err) atomicAdd(&d.counters[CNT_ERRORS], 1);
     }
@@ -546,6 +547,7 @@ void tg_engine_destroy(tg_ctx* ctx) {
     void* ptrs[] = {e->dev.arena, e->dev.ctl, e->dev.rng, e->dev.path_nodes, e->dev.path_len, e->dev.path_row, e->dev.row_game,
                     e->dev.obs, e->dev.policy, e->dev.value, e->dev.counters, e->d_noise, e->d_i32, e->d_f32, e->d_u8};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (hipEvent_t ev : e->tev) (void)hipEventDestroy(ev);
     tg_net_destroy(ctx);
     delete e;
     ctx->eng = nullptr;
@@ -700,7 +702,10 @@ int tg_sp_collect(tg_ctx* ctx, int32_t* n_active, int32_t* n_rows) {
     Engine* e = ctx->eng;
     if (e->batch_kind != BATCH_NONE) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_collect: an evaluation batch is pending");
     TG_HIP(ctx, hipMemsetAsync(e->dev.counters, 0, sizeof(int32_t) * 2, ctx->stream));     // CNT_ROWS, CNT_ACTIVE
+    const bool timed = e->tprof && e->tev_used + 4 <= e->tev.size();
+    if (timed) { TG_HIP(ctx, hipEventRecord(e->tev[e->tev_used], ctx->stream)); }
     TG_LAUNCH(ctx, k_collect, e->G, e->dev);
+    if (timed) { TG_HIP(ctx, hipEventRecord(e->tev[e->tev_used + 1], ctx->stream)); e->tev_kind[e->tev_used / 2] = 0; e->tev_used += 2; e->tree_waves++; }
     int32_t cnt[CNT_N];
     int rc = read_counters(ctx, cnt);
     if (rc) return rc;
@@ -717,7 +722,10 @@ int tg_sp_absorb(tg_ctx* ctx) {
     Engine* e = ctx->eng;
     if (e->batch_kind != BATCH_LEAVES) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_absorb: no leaf batch pending");
     if (!e->batch_ready) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_absorb: batch not evaluated");
+    const bool timed = e->tprof && e->tev_used + 2 <= e->tev.size();
+    if (timed) { TG_HIP(ctx, hipEventRecord(e->tev[e->tev_used], ctx->stream)); }
     TG_LAUNCH(ctx, k_absorb, e->G, e->dev);
+    if (timed) { TG_HIP(ctx, hipEventRecord(e->tev[e->tev_used + 1], ctx->stream)); e->tev_kind[e->tev_used / 2] = 1; e->tev_used += 2; }
     e->batch_kind = BATCH_NONE; e->batch_ready = false;
     return TG_OK;
 }
@@ -825,6 +833,42 @@ int tg_sp_stats(tg_ctx* ctx, uint64_t* sims, uint64_t* evals, uint64_t* depth_su
     }
     if (sims) *sims = s; if (evals) *evals = ev; if (depth_sum) *depth_sum = ds; if (tie_draws) *tie_draws = td;
     if (errors) *errors = er; if (max_slots) *max_slots = ms;
+    return TG_OK;
+}
+
+// HIP-event time of the tree stage (k_collect / k_absorb launches since tg_prof_enable(ctx, 1, n)) and the PUCT fan-out counter
+int tg_prof_read_tree(tg_ctx* ctx, double* collect_ms, double* absorb_ms, int64_t* waves, uint64_t* children_scored) {
+    NEED_ENGINE(ctx);
+    Engine* e = ctx->eng;
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i + 1 < e->tev_used; i += 2) {
+        float t = 0; TG_HIP(ctx, hipEventElapsedTime(&t, e->tev[i], e->tev[i + 1]));
+        (e->tev_kind[i / 2] ? e->absorb_ms : e->collect_ms) += t;
+    }
+    e->tev_used = 0;
+    if (collect_ms) *collect_ms = e->collect_ms;
+    if (absorb_ms) *absorb_ms = e->absorb_ms;
+    if (waves) *waves = e->tree_waves;
+    if (children_scored) {
+        std::vector<GameCtl> h(e->G);
+        TG_HIP(ctx, hipMemcpy(h.data(), e->dev.ctl, sizeof(GameCtl) * e->G, hipMemcpyDeviceToHost));
+        uint64_t cs = 0; for (const GameCtl& c : h) cs += c.child_sum;
+        *children_scored = cs;
+    }
+    return TG_OK;
+}
+
+int tg_prof_enable_tree(tg_ctx* ctx, int on, int max_waves) {
+    NEED_ENGINE(ctx);
+    Engine* e = ctx->eng;
+    TG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    if (on) {
+        const size_t want = 4 * (size_t)(max_waves > 0 ? max_waves : 4096);
+        while (e->tev.size() < want) { hipEvent_t ev; TG_HIP(ctx, hipEventCreate(&ev)); e->tev.push_back(ev); }
+        e->tev_kind.assign(e->tev.size() / 2 + 1, 0);
+        e->tev_used = 0; e->collect_ms = e->absorb_ms = 0; e->tree_waves = 0;
+    }
+    e->tprof = on != 0;
     return TG_OK;
 }
 

@@ -392,11 +392,18 @@ __global__ __launch_bounds__(256, sd_wg_per_cu(S, F)) void k_conv3x3_sd(const fl
             b[t] = *reinterpret_cast<const f32x4*>(src);
         }
     };
+    // EPI 1: the accumulators START from the residual -- CT*NPT loads per wave that fly while the first DMAs land (they are older
+    // than the DMAs, so the counted wait below covers them) -- and the epilogue has no load behind its stores
     f32x4 acc[CT][NPT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+    for (int t = 0; t < NPT; ++t) {
+        const int m = m0 + (wave * NPT + t) * 16 + j;
 #pragma unroll
-        for (int t = 0; t < NPT; ++t) acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ct = 0; ct < CT; ++ct) {
+            acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (EPI == 1 && m < M) acc[ct][t] = *reinterpret_cast<const f32x4*>(res + (size_t)m * F + ct * 16 + kq * 4);
+        }
+    }
 
 #ifdef TG_SD_STAMP
     unsigned long long t_start, t_pro, t_a, t_b, t_c, t_loop, t_end, s_dma = 0, s_bar = 0;
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(256, sd_wg_per_cu(S, F)) void k_conv3x3_sd(const fl
     int mrow[NPT];
 #pragma unroll
     for (int t = 0; t < NPT; ++t) mrow[t] = m0 + (wave * NPT + t) * 16 + j;
-    conv_epilogue<F, CT, NPT, EPI>(acc, mrow, M, 0, kq, out, res, out2, par);
+    conv_epilogue<F, CT, NPT, (EPI == 1 ? 2 : EPI)>(acc, mrow, M, 0, kq, out, res, out2, par);
 #ifdef TG_SD_STAMP
     TG_STAMP(t_end);
     if (lane == 0) {

@@ -56,6 +56,8 @@ struct GameCtl {
     unsigned long long evals;       // leaves sent to the evaluator
     unsigned long long depth_sum;   // sum of selection depths
     unsigned long long tie_draws;   // RNG words consumed by tie breaks
+    unsigned long long child_sum;   // children scored by PUCT, summed over selection levels (mean fan-out = child_sum / depth_sum)
+    unsigned long long pad1;
 };
 
 struct SearchCfg {

@@ -22,9 +22,9 @@ def _engine(fn, G, sims, **kw):
     return SelfPlayEngine(G, num_simulation=sims, evaluator=fn, **kw)
 
 
-def _replay_fixture(blob, tag, fn, max_moves=None):
+def _replay_fixture(blob, tag, fn, max_moves=None, **kw):
     seed, sims = int(tag.split("_")[1][1:]), int(tag.split("_")[2][1:])
-    eng = _engine(fn, 1, sims)
+    eng = _engine(fn, 1, sims, **kw)
     eng.reset([seed])
     n_moves = len(blob[f"{tag}/action"])
     if max_moves:
@@ -54,6 +54,21 @@ def test_reference_full_games(golden_dir, tag):
     score, terr, win = eng.final()
     assert score[0] == blob[f"{tag}/final_score"] and (terr[0].astype(np.int8) == blob[f"{tag}/final_terr"]).all()
     assert win[0] == blob[f"{tag}/winner"]
+    assert eng.stats()["errors"] == 0
+
+
+@pytest.mark.parametrize("tag,full", [("sharp_s21_n48", True), ("flat_s22_n24", True), ("sharp_s23_n160", False)])
+def test_reference_19x19_search(golden_dir, tag, full):
+    """Board size 19 against vectors recorded from the reference WP_MCTS on a 19x19 build of its engine
+    (tests/golden/gen_search19.py): visit counts, moves, pi, RNG position per move; final score / territory of full games."""
+    blob = _load(golden_dir, "search_s19.npz")
+    eng = _replay_fixture(blob, tag, evaluators.BY_NAME[tag.split("_")[0]], board_size=19, max_step=int(blob["max_step"]))
+    key, _ = eng.rng_state(0)
+    assert (key == blob[f"{tag}/final_key"]).all()
+    if full:
+        score, terr, win = eng.final()
+        assert score[0] == blob[f"{tag}/final_score"] and (terr[0].astype(np.int8) == blob[f"{tag}/final_terr"]).all()
+        assert win[0] == blob[f"{tag}/winner"]
     assert eng.stats()["errors"] == 0
 
 

@@ -16,19 +16,19 @@ def _load(golden_dir, name):
         return {k: z[k] for k in z.files}
 
 
-def replay_case(blob, tag, fn, max_moves=None):
+def replay_case(blob, tag, fn, max_moves=None, size=9, max_step=120):
     name, seed, sims = tag.split("_")
     seed, sims = int(seed[1:]), int(sims[1:])
-    env = OracleGoEnv()
+    env = OracleGoEnv(board_size=size, max_step=max_step)
     rng = np.random.RandomState(seed)
-    s = OracleSearch(env, fn, rng, num_simulation=sims)
+    s = OracleSearch(env, fn, rng, num_simulation=sims, board_size=size)
     n_moves = len(blob[f"{tag}/action"])
     if max_moves:
         n_moves = min(n_moves, max_moves)
     for m in range(n_moves):
         n0 = s.root.n
         a, pi, obs, info = s.search_move()
-        raw = np.array([s.root.kids[i].n if i in s.root.kids else 0 for i in range(82)])
+        raw = np.array([s.root.kids[i].n if i in s.root.kids else 0 for i in range(size * size + 1)])
         assert n0 == blob[f"{tag}/n0"][m], (tag, m)
         assert (raw == blob[f"{tag}/counts"][m]).all(), (tag, m)
         assert a == blob[f"{tag}/action"][m], (tag, m)
@@ -55,6 +55,19 @@ def test_full_games(golden_dir, tag):
 def test_deep_search(golden_dir, tag, moves):
     blob = _load(golden_dir, "search_analytic.npz")
     replay_case(blob, tag, evaluators.BY_NAME[tag.split("_")[0]], max_moves=moves)
+
+
+@pytest.mark.parametrize("tag,full", [("sharp_s21_n48", True), ("flat_s22_n24", True), ("sharp_s23_n160", False)])
+def test_19x19_search_matches_reference(golden_dir, tag, full):
+    """The same observables at board size 19, recorded from the reference WP_MCTS running on a 19x19 build of its engine
+    (tests/golden/gen_search19.py): two games to the ply limit and one deeper search."""
+    blob = _load(golden_dir, "search_s19.npz")
+    s, rng = replay_case(blob, tag, evaluators.BY_NAME[tag.split("_")[0]], size=19, max_step=int(blob["max_step"]))
+    assert (rng.get_state()[1] == blob[f"{tag}/final_key"]).all()
+    if full:
+        score, terr = s.env.getScoreAndTerritory(s.root.state)
+        assert score == blob[f"{tag}/final_score"] and (terr.astype(np.int8) == blob[f"{tag}/final_terr"]).all()
+        assert s.env.getWinner(s.root.state) == blob[f"{tag}/winner"]
 
 
 def test_replayed_network(golden_dir):

@@ -129,3 +129,24 @@ def test_device_replay_sampler_equals_reference_buffer_plus_trainer_stacking():
     ds2, dp2, dz2, do2 = dev.sample(32)
     assert ds2.shape == (32, 10, 9, 9) and np.allclose(dp2.sum(1), 1, atol=1e-6)
     dev.close()
+
+
+def test_fp16_self_play_through_the_host_mirror():
+    """BASELINE config 5's arithmetic end to end: Config.inference_dtype = "f16" reaches tg_config.net_precision, the batched
+    self-play loop runs on the fp16 tower, games finish and produce the reference's target tuples (counts consistent, pi a
+    distribution, z = +-1)."""
+    from transgo_amd import model
+    from transgo_amd.configure import Config
+    from transgo_amd.self_play import BatchedSelfPlay
+    cfg = Config(num_simulation=24, num_features=128, num_blocks=2, max_step=12, inference_dtype="f16")
+    sp = BatchedSelfPlay(cfg, 16)
+    sp.set_weights(model.random_weights(9, 10, 128, 2, seed=3))
+    sp.start()
+    finished = []
+    for _ in range(14):
+        finished += sp.step()
+        if len(finished) >= 16:
+            break
+    assert len(finished) >= 16 and sp.engine.stats()["errors"] == 0
+    obs, pi, z, own = sp.targets(finished[0])[0]
+    assert obs.shape == (10, 9, 9) and abs(pi.sum() - 1.0) < 1e-9 and z in (-1.0, 1.0) and own.shape == (81,)

@@ -194,8 +194,8 @@ def main():
         # HBM bytes per launch of the dominant kernel come from PMC passes (separate rocprofv3 runs, committed under profiles/);
         # they only describe the configuration they were collected on
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-        if os.path.exists(tfile) and (S, a.filters, a.games, a.dtype) == (9, 128, 4096, "f32"):
+        tfile = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json" if a.dtype == "f32" else "r1_pmc_traffic_f16.json")
+        if os.path.exists(tfile) and (S, a.filters, a.games) == (9, 128, 4096):
             with open(tfile) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch_mean")
         value = sims_all / dt
@@ -215,8 +215,8 @@ def main():
                        "step": "one move of every board (search + move selection + re-root + gather of finished games)"},
             "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(conv_tflops / peak, 4), "traffic": traffic,
-                         "traffic_note": ("HBM bytes per full-batch launch, FETCH_SIZE x2 + WRITE_SIZE (profiles/r1_pmc_traffic.json)"
-                                          if traffic is not None else "PMC traffic was collected for the default f32 workload only"),
+                         "traffic_note": (f"HBM bytes per full-batch launch, FETCH_SIZE x2 + WRITE_SIZE (profiles/{os.path.basename(tfile)})"
+                                          if traffic is not None else "PMC traffic was collected for the 9x9 / 128-filter / 4096-board workload only"),
                          "kernel": kernel_name(S, a.filters, a.dtype),
                          "launches": int(nl.value), "avg_launch_ms": round(ms.value / max(1, nl.value), 4)},
             "roofline_tree": tree,

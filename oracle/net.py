@@ -161,10 +161,10 @@ def seeded_tower(board_size=9, input_dim=10, filters=128, blocks=6, seed=1234):
 
 def half_storage_forward(net, x):
     """What an fp16-storage / f32-accumulate evaluation of `net` (a TowerNetwork) computes, with the rounding points of the
-    HIP fp16 chain (BASELINE config 5): the stem and the heads run in f32; inside a PreActBlock the conv INPUTS
-    relu(bn1(x)) and relu(bn2(conv1(.))) and the conv weights (bn2 folded into conv_1, fold evaluated in f64 and stored
-    as f32 first) are rounded to fp16 (round to nearest even), products accumulate in f32, and the residual stream x
-    stays f32.  Only the accumulation order inside a convolution is left free."""
+    HIP fp16 chain (BASELINE config 5): every convolution (stem, tower, the two head convs) takes fp16 weights (BatchNorm
+    folded in f64, stored as f32, then rounded to nearest even) and fp16 inputs, products accumulate in f32; the residual
+    stream and the dense heads stay f32.  Conv inputs: the 0/1 planes (exact), relu(bn1(x)) and relu(bn2(conv1(.))) inside a
+    PreActBlock, relu(bn_res_end(x)) for the head convs.  Only the accumulation order inside a convolution is left free."""
     body = net.main_network
     P = body.S * body.S
     q = lambda t: t.half().float()
@@ -173,8 +173,15 @@ def half_storage_forward(net, x):
         s = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
         return s, bn.bias.double() - bn.running_mean.double() * s
 
+    def conv_bn_relu(block, inp):                      # ConvBnRelu with its BN folded into the fp16 weights
+        conv, bn = block.conv[0], block.conv[1]
+        s, t = fold(bn)
+        w = (conv.weight.double() * s[:, None, None, None]).float()
+        b = (conv.bias.double() * s + t).float()
+        return F.relu(F.conv2d(inp, q(w), b, 1, 1))
+
     with torch.no_grad():
-        y = body.conv1(x)
+        y = conv_bn_relu(body.conv1, x)
         for b in body.res_blocks:
             s1, t1 = fold(b.batchnormlize_1)
             s2, t2 = fold(b.batchnormlize_2)
@@ -183,9 +190,10 @@ def half_storage_forward(net, x):
             a = q(F.relu(y * s1.float()[None, :, None, None] + t1.float()[None, :, None, None]))
             h = q(F.relu(F.conv2d(a, q(w1), b1, 1, 1)))
             y = F.conv2d(h, q(b.conv_2.weight), b.conv_2.bias, 1, 1) + y
-        z = F.relu(body.bn_res_end(y))
-        hid = F.relu(body.fc_val_own(body.conv_val_own(z).view(-1, 2 * P)))
+        se, te = fold(body.bn_res_end)
+        z = q(F.relu(y * se.float()[None, :, None, None] + te.float()[None, :, None, None]))
+        hid = F.relu(body.fc_val_own(conv_bn_relu(body.conv_val_own, z).view(-1, 2 * P)))
         val = torch.tanh(body.fc_val(hid))
         own = torch.tanh(body.fc_own(hid))
-        act = torch.softmax(body.fc_act(body.conv_act(z).view(-1, 4 * P)), -1)
+        act = torch.softmax(body.fc_act(conv_bn_relu(body.conv_act, z).view(-1, 4 * P)), -1)
     return act, val, own

@@ -40,6 +40,7 @@ struct Net {
     float* bufQ = nullptr; float* hca = nullptr;   // q|k|v projections [rows][P][1.5F]; policy head conv output
     float* bufAct = nullptr;                       // pre-activated input of the next conv (DMA path)
     int prec = 0;                                  // cfg.net_precision: 0 = f32, 1 = fp16 storage + f32 accumulate (k_conv3x3_h)
+    _Float16* stem_h = nullptr; _Float16* head_h = nullptr; _Float16* x0h = nullptr;   // fp16 path: stem [2*9][F][32] (16 planes padded to 64), head [F/32*9][16][32], input [rows][P][64]
     _Float16* wh = nullptr; _Float16* act16 = nullptr; _Float16* h16 = nullptr;   // fp16 path: weights [2*NB][F/32*9][F][32], activations [rows][P][F]
     int dma = 0;                                   // attention-free F=128/256 f32 tower: 1 = k_conv3x3_sd chain (default), 0 = k_conv3x3 (TG_DMA_CONV=0)
     ConvW head; const float* w_vo = nullptr; const float* b_vo = nullptr; const float* w_v = nullptr; const float* b_v = nullptr;
@@ -478,6 +479,7 @@ __global__ __launch_bounds__(256, sd_wg_per_cu(S, F)) void k_conv3x3_sd(const fl
 // rate), so the kernel is shaped by what feeds the pipe rather than by the pipe; see k_conv3x3_h2 below.
 // EPI 0: out16 = half(relu(acc + bias))     EPI 1: out32 = acc + bias + res ; out16 = half(relu(out32 * s2 + t2)) (optional)
 // EPI 2: as EPI 1 with the residual already inside acc (k_conv3x3_h2 starts its accumulators from it)
+// EPI 4 (stem): out32 = relu(acc + bias) ; out16 = half(relu(out32 * s2 + t2))
 #ifndef TG_H_DA
 #define TG_H_DA 4
 #endif
@@ -531,6 +533,10 @@ __device__ __forceinline__ void conv_epilogue_h(f32x4 (&acc)[CT][NPT], const int
                     TG_NT_STORE(u, reinterpret_cast<h4*>(out16 + (size_t)mrow[t] * F + col));
                 } else {
                     if (EPI == 1) v = v + r[c & 1][i];
+                    if (EPI == 4) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    }
                     TG_NT_STORE(v, reinterpret_cast<f32x4*>(out32 + (size_t)mrow[t] * F + col));
                     if (out16) {
                         const f32x4 sc = *reinterpret_cast<const f32x4*>(par + pstride + lc);
@@ -554,19 +560,19 @@ __device__ __forceinline__ void conv_epilogue_h(f32x4 (&acc)[CT][NPT], const int
 // reads chip-wide at 1 PFLOP/s).  Measured shares of a 0.88-ms launch (8192 boards, F=256; ablation builds): MFMA loop alone
 // 0.44, DMA issue + traffic 0.17, epilogue 0.22, B-fragment addressing + reads 0.09, barriers 0.03, A reads 0.03.
 // An 8-wave 256x256 tile with one workgroup per CU (64-channel stages) measured 827 vs 888 TFLOP/s for this shape.
-template <int S, int F, int EPI>
+template <int S, int CIN, int F, int EPI>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restrict__ in, float* __restrict__ out32,
                                                        _Float16* __restrict__ out16, const float* __restrict__ res,
                                                        const _Float16* __restrict__ Ws, const float* __restrict__ bias,
                                                        const float* __restrict__ s2, const float* __restrict__ t2, int M, int nblk) {
     constexpr int P = S * S, HALO = S + 1, KC = 32, NW = 4, NPT = 4, TM = 64 * NW, NCO = 128, CT = NCO / 16, COS = F / NCO;
     constexpr int NCHK = KC / 8, RPP = 64 / NCHK;                       // 4 chunks per 64-B row, 16 rows per 1-KB DMA piece
-    constexpr int NSL = F / KC, NST = NSL * 9, NPAIR = NST / 2, NSLOT = 4;
+    constexpr int NSL = CIN / KC, NST = NSL * 9, NPAIR = NST / 2, NSLOT = 4;        // CIN input channels (row stride), F output channels
     constexpr int NROW = TM + 2 * HALO;
     constexpr int NXP = (NROW + RPP - 1) / RPP;
     constexpr int NXQ = (NXP + NW - 1) / NW;
     constexpr int WPW = NCO / RPP / NW;                                 // weight pieces per wave per stage (2)
-    static_assert(NST % 2 == 0 && F % NCO == 0 && NCO % (RPP * NW) == 0, "tile geometry");
+    static_assert(NST % 2 == 0 && CIN % KC == 0 && F % NCO == 0 && NCO % (RPP * NW) == 0, "tile geometry");
     __shared__ __attribute__((aligned(16))) _Float16 xs[2][NXP * RPP * KC];
     __shared__ __attribute__((aligned(16))) _Float16 ws[NSLOT][NCO * KC];
     __shared__ __attribute__((aligned(16))) float par[3 * NCO];
@@ -587,11 +593,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
     for (int i = tid; i < NCO; i += 256) {
         par[i] = bias[co0 + i]; par[NCO + i] = out16 && s2 ? s2[co0 + i] : 0.f; par[2 * NCO + i] = out16 && t2 ? t2[co0 + i] : 0.f;
     }
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in), 0, M * F * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in), 0, M * CIN * 2, 0x00020000);
     // a piece is 16 rows x 64 B: lane -> row prow, physical chunk pchk, which holds logical chunk pchk ^ swz64(row); pieces start at
     // multiples of 16 rows, so the lane's share of every source address is ONE register (the rest is wave-uniform)
     const int prow = lane / NCHK, pchk = lane % NCHK;
-    const int lane_x = (prow * F + (pchk ^ swz64(prow)) * 8) * 2;         // bytes, activation rows are F halfs apart
+    const int lane_x = (prow * CIN + (pchk ^ swz64(prow)) * 8) * 2;       // bytes, activation rows are CIN halfs apart
     const int lane_w = prow * KC + (pchk ^ swz64(prow)) * 8;              // halfs, stage-tile rows are KC halfs apart
     auto dma_x = [&](int sl) {
 #pragma unroll
@@ -600,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
             if (q < NXP) {                                               // wave-uniform
                 if (q * RPP + prow < NROW) {
                     // the whole offset must travel in voffset: soffset is not range-checked, and rows outside the tensor must read 0
-                    const int voff = ((m0 - HALO + q * RPP) * F + sl * KC) * 2 + lane_x;
+                    const int voff = ((m0 - HALO + q * RPP) * CIN + sl * KC) * 2 + lane_x;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (tg_lds_void*)(&xs[sl & 1][q * 512]), 16, voff, 0, 0, 0);
                 }
             }
@@ -746,7 +752,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
         while (nb < nblk && tile_m0(nb) >= M) nb += gridDim.x;
         const bool have_next = nb < nblk;
         if (have_next) { bid = nb; m0 = tile_m0(nb); prologue(); }
-        conv_epilogue_h<F, CT, NPT, (EPI == 1 ? 2 : EPI)>(acc, mrow, M, co0, kq, out32, out16, res, par, NCO);
+        conv_epilogue_h<F, CT, NPT, (EPI == 1 ? 2 : EPI)>(acc, mrow, M, co0, kq, out32, out16, res, par, NCO);   // EPI 4: the stem
 #ifdef TG_SD_STAMP
         TG_STAMP(t_end);
         if (lane == 0) {
@@ -759,16 +765,127 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
     }
 }
 
-// stage-ordered fp16 copy of one F->F conv: dst[(slice*9 + tap)][cout][KC] = half(w[tap][cout][slice*KC + c])
-__global__ __launch_bounds__(256) void k_restage_half(const float* __restrict__ w, _Float16* __restrict__ dst, int F, int KC) {
-    const size_t total = (size_t)9 * F * F;
+// stage-ordered fp16 copy of a conv: dst[(slice*9 + tap)][cout][KC] = half(w[tap][cout][slice*KC + c]) for c < cin_src, else 0
+// (w is [9][COUT][cin_src]; the destination covers cin_dst >= cin_src channels: the stem pads its 16 input planes to 64)
+__global__ __launch_bounds__(256) void k_restage_half(const float* __restrict__ w, _Float16* __restrict__ dst, int COUT, int cin_src,
+                                                      int cin_dst, int KC) {
+    const size_t total = (size_t)9 * COUT * cin_dst;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % KC);
         const size_t r = i / KC;
-        const int co = (int)(r % F);
-        const int st = (int)(r / F);
+        const int co = (int)(r % COUT);
+        const int st = (int)(r / COUT);
         const int sl = st / 9, tap = st % 9;
-        dst[i] = (_Float16)w[((size_t)tap * F + co) * F + sl * KC + c];
+        const int ci = sl * KC + c;
+        dst[i] = ci < cin_src ? (_Float16)w[((size_t)tap * COUT + co) * cin_src + ci] : (_Float16)0.f;
+    }
+}
+
+// network input for the fp16 stem: obs f32 [rows][C][P] (planes of 0/1, exact in fp16) -> x0h [rows*P][64] halfs, channel-minor
+template <int S>
+__global__ __launch_bounds__(256) void k_obs_to_rows_h(const float* __restrict__ obs, _Float16* __restrict__ x0, int rows, int C) {
+    constexpr int P = S * S;
+    const size_t total = (size_t)rows * P * 64;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i & 63);
+        const size_t m = i >> 6;
+        const int p = (int)(m % P);
+        const size_t r = m / P;
+        x0[i] = c < C ? (_Float16)obs[(r * C + c) * P + p] : (_Float16)0.f;
+    }
+}
+
+// fp16 head conv (F -> 16 couts: value/ownership and policy convs with their BNs folded, model.py:65-76): out[m][16] = relu(acc +
+// bias) in f32 for k_heads.  One 16-cout tile makes this an LDS-read-bound kernel (one B fragment per MFMA), not an MFMA-bound
+// one: the 9 A fragments of a 32-channel slice live in registers, slabs and the slice's 9-KB weight block are double-buffered
+// LDS-DMA targets, one barrier per slice.  Same slab image, swizzle and masking as k_conv3x3_h2.
+template <int S, int F>
+__global__ __launch_bounds__(256, 2) void k_head_h(const _Float16* __restrict__ in, float* __restrict__ out,
+                                                   const _Float16* __restrict__ Wh, const float* __restrict__ bias, int M) {
+    constexpr int P = S * S, HALO = S + 1, KC = 32, NW = 4, NPT = 4, TM = 64 * NW, NCHK = 4, RPP = 16;
+    constexpr int NSL = F / KC, NROW = TM + 2 * HALO, NXP = (NROW + RPP - 1) / RPP, NXQ = (NXP + NW - 1) / NW;
+    __shared__ __attribute__((aligned(16))) _Float16 xs[2][NXP * RPP * KC];
+    __shared__ __attribute__((aligned(16))) _Float16 wsl[2][9 * 16 * KC];
+    __shared__ __attribute__((aligned(16))) float zrow[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * TM;
+    if (tid < 4) zrow[tid] = 0.f;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in), 0, M * F * 2, 0x00020000);
+    const int prow = lane / NCHK, pchk = lane % NCHK;
+    const int lane_x = (prow * F + (pchk ^ swz64(prow)) * 8) * 2;
+    const int lane_w = prow * KC + (pchk ^ swz64(prow)) * 8;
+    auto dma = [&](int sl) {                                              // slab and weight block of slice sl
+#pragma unroll
+        for (int i = 0; i < NXQ; ++i) {
+            const int q = wave * NXQ + i;
+            if (q < NXP && q * RPP + prow < NROW) {
+                const int voff = ((m0 - HALO + q * RPP) * F + sl * KC) * 2 + lane_x;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (tg_lds_void*)(&xs[sl & 1][q * 512]), 16, voff, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+            if (tap % NW == wave)                                        // one 1-KB piece per tap: 16 couts x 32 channels
+                __builtin_amdgcn_global_load_lds(Wh + ((size_t)sl * 9 + tap) * 16 * KC + lane_w, (tg_lds_void*)(&wsl[sl & 1][tap * 512]), 16, 0, 0);
+    };
+    unsigned vmask[NPT]; int vrow[NPT];
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) {
+        const int m = m0 + (wave * NPT + t) * 16 + j;
+        unsigned mk = 0;
+        if (m < M) {
+            const int p = m % P, x = p % S, y = p / S;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                if (yy >= 0 && yy < S && xx >= 0 && xx < S) mk |= 1u << tap;
+            }
+        }
+        vmask[t] = mk; vrow[t] = (wave * NPT + t) * 16 + j + HALO;
+    }
+    const int aoff = j * KC + ((kq ^ swz64(j)) << 3);
+    const int nx_mine = NXP - wave * NXQ < 0 ? 0 : NXP - wave * NXQ > NXQ ? NXQ : NXP - wave * NXQ;
+    const int cnt_mine = nx_mine + (wave == 0 ? 3 : 2);                  // DMA instructions this wave issues per slice (taps w, w+4, w+8 < 9)
+    f32x4 acc[NPT];
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dma(0);
+    if (NSL > 1) dma(1);
+#pragma unroll 1
+    for (int sl = 0; sl < NSL; ++sl) {
+        // slice sl must have landed; the only younger DMAs of this wave are its pieces of slice sl+1
+        if (sl + 1 < NSL) vmcnt_uniform<NXQ + 3>(cnt_mine); else TG_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        f32x4 a[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) a[tap] = *reinterpret_cast<const f32x4*>(wsl[sl & 1] + tap * 512 + aoff);
+        const _Float16* base = xs[sl & 1];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int toff = (tap / 3 - 1) * S + (tap % 3 - 1);
+#pragma unroll
+            for (int t = 0; t < NPT; ++t) {
+                const int R = vrow[t] + toff;
+                const _Float16* src = ((vmask[t] >> tap) & 1) ? base + R * KC + ((kq ^ swz64(R)) << 3) : reinterpret_cast<const _Float16*>(zrow);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(src);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a[tap]), __builtin_bit_cast(h8, b), acc[t], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_barrier();                                     // every wave is done with buffers sl & 1
+        if (sl + 2 < NSL) dma(sl + 2);
+    }
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + kq * 4);
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) {
+        const int m = m0 + (wave * NPT + t) * 16 + j;
+        if (m < M) {
+            f32x4 v = acc[t] + bv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            *reinterpret_cast<f32x4*>(out + (size_t)m * 16 + kq * 4) = v;
+        }
     }
 }
 
@@ -894,37 +1011,41 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
     const int grid_f = (M + 64 * NPT - 1) / (64 * NPT);
     const double conv_flops = 2.0 * 9.0 * (double)F * (double)F * (double)M;
     int g0 = (int)(((size_t)M * 16 + 255) / 256); if (g0 > 65535) g0 = 65535;
-    hipLaunchKernelGGL((k_obs_to_rows<S>), dim3(g0), dim3(256), 0, st, obs, n->x0, rows, n->C);
+    if (n->prec == 0) hipLaunchKernelGGL((k_obs_to_rows<S>), dim3(g0), dim3(256), 0, st, obs, n->x0, rows, n->C);
     float* x = n->bufA; float* y = n->bufB;
     if constexpr (F == 128 || F == 256) {
         if (n->prec == 1) {
-            // fp16 chain: trunk x/y stay f32 (residual stream), conv inputs act16/h16 are fp16, stem and heads run in f32
+            // fp16 chain: every conv (stem, tower, head conv) takes fp16 operands and accumulates in f32; the residual stream x/y and
+            // the small dense heads (k_heads) stay f32
             if ((long long)M * F * 2 >= (1ll << 31)) TG_FAIL(ctx, TG_ERR_ARG, "fp16 path: rows * P * F * 2 bytes must stay below 2 GiB per activation buffer");
             const int grid_h = (M + 255) / 256;                                      // 256-row tiles
             constexpr int COS = F / 128;
             const int nblk_h2 = COS == 1 ? grid_h : (grid_h + 7) / 8 * 8 * COS;      // (row tile, cout part) blocks
             const int grid_h2 = nblk_h2 < TG_H2_GRID ? nblk_h2 : TG_H2_GRID;       // persistent: 2 workgroups per CU x 256 CUs
             const size_t nb = n->blocks.size();
-            // stem in f32; its epilogue also writes the first conv input relu(bn1(x)) as fp16
-            hipLaunchKernelGGL((k_conv3x3<S, 16, F, false, 0, 9, 2, true>), dim3(grid), dim3(256), 0, st, (const float*)n->x0, x,
-                               (const float*)nullptr, n->stem.w, n->stem.b, (const float*)nullptr, (const float*)nullptr, M,
-                               nb ? reinterpret_cast<float*>(n->act16) : (float*)nullptr, nb ? n->blocks[0].s1 : nullptr, nb ? n->blocks[0].t1 : nullptr);
+            // stem on the fp16 matrix cores too (input planes are 0/1, exact in fp16; 16 planes padded to 64 channels = 18 stages):
+            // writes the f32 residual stream x and the first conv input relu(bn_next(x)) as fp16
+            int g0h = (int)(((size_t)M * 64 + 255) / 256); if (g0h > 65535) g0h = 65535;
+            hipLaunchKernelGGL((k_obs_to_rows_h<S>), dim3(g0h), dim3(256), 0, st, obs, n->x0h, rows, n->C);
+            hipLaunchKernelGGL((k_conv3x3_h2<S, 64, F, 4>), dim3(grid_h2), dim3(256), 0, st, (const _Float16*)n->x0h, x, n->act16,
+                               (const float*)nullptr, (const _Float16*)n->stem_h, n->stem.b, nb ? n->blocks[0].s1 : n->s_end,
+                               nb ? n->blocks[0].t1 : n->t_end, M, nblk_h2);
             for (size_t i = 0; i < nb; ++i) {
                 const BlockW& b = n->blocks[i];
                 const bool last = i + 1 == nb;
-                const float* sn = last ? nullptr : n->blocks[i + 1].s1;
-                const float* tn = last ? nullptr : n->blocks[i + 1].t1;
-                _Float16* const a16 = last ? (_Float16*)nullptr : n->act16;
+                const float* sn = last ? n->s_end : n->blocks[i + 1].s1;          // the last block activates for the head conv
+                const float* tn = last ? n->t_end : n->blocks[i + 1].t1;
+                _Float16* const a16 = n->act16;
                 { ProfScope ps(n, st, conv_flops);
-                  hipLaunchKernelGGL((k_conv3x3_h2<S, F, 0>), dim3(grid_h2), dim3(256), 0, st, (const _Float16*)n->act16,
+                  hipLaunchKernelGGL((k_conv3x3_h2<S, F, F, 0>), dim3(grid_h2), dim3(256), 0, st, (const _Float16*)n->act16,
                                      (float*)nullptr, n->h16, (const float*)nullptr, b.h1, b.c1.b, (const float*)nullptr, (const float*)nullptr, M, nblk_h2); }
                 { ProfScope ps(n, st, conv_flops);
-                  hipLaunchKernelGGL((k_conv3x3_h2<S, F, 1>), dim3(grid_h2), dim3(256), 0, st, (const _Float16*)n->h16,
+                  hipLaunchKernelGGL((k_conv3x3_h2<S, F, F, 1>), dim3(grid_h2), dim3(256), 0, st, (const _Float16*)n->h16,
                                      y, a16, (const float*)x, b.h2, b.c2.b, sn, tn, M, nblk_h2); }
                 float* t = x; x = y; y = t;
             }
-            hipLaunchKernelGGL((k_conv3x3<S, F, 16, true, 0>), dim3(grid), dim3(256), 0, st, (const float*)x, n->hc,
-                               (const float*)nullptr, n->head.w, n->head.b, n->s_end, n->t_end, M);
+            hipLaunchKernelGGL((k_head_h<S, F>), dim3(grid_h), dim3(256), 0, st, (const _Float16*)n->act16, n->hc,
+                               (const _Float16*)n->head_h, n->head.b, M);
             hipLaunchKernelGGL((k_heads<S>), dim3(rows), dim3(256), 0, st, (const float*)n->hc, (const float*)n->hc, n->w_vo, n->b_vo,
                                n->w_v, n->b_v, n->w_o, n->b_o, n->w_a, n->b_a, policy, value, own);
             TG_HIP(ctx, hipGetLastError());
@@ -1114,6 +1235,9 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
             TG_HIP(ctx, hipMalloc((void**)&n->wh, sizeof(_Float16) * wcopy));
             TG_HIP(ctx, hipMalloc((void**)&n->act16, act / 2));
             TG_HIP(ctx, hipMalloc((void**)&n->h16, act / 2));
+            TG_HIP(ctx, hipMalloc((void**)&n->stem_h, sizeof(_Float16) * 9 * (size_t)F * 64));
+            TG_HIP(ctx, hipMalloc((void**)&n->head_h, sizeof(_Float16) * 9 * 16 * (size_t)F));
+            TG_HIP(ctx, hipMalloc((void**)&n->x0h, sizeof(_Float16) * (size_t)rows_cap * P * 64));
         }
         const float* p = n->blob;
         auto take = [&](size_t k) { const float* q = p; p += k; return q; };
@@ -1158,10 +1282,12 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
         for (size_t i = 0; i < n->blocks.size(); ++i) {
             BlockW& b = n->blocks[i];
             _Float16* d1 = n->wh + (2 * i) * per; _Float16* d2 = n->wh + (2 * i + 1) * per;
-            hipLaunchKernelGGL(k_restage_half, dim3(1024), dim3(256), 0, ctx->stream, b.c1.w, d1, F, 32);     // k_conv3x3_h2: 32-channel stages
-            hipLaunchKernelGGL(k_restage_half, dim3(1024), dim3(256), 0, ctx->stream, b.c2.w, d2, F, 32);
+            hipLaunchKernelGGL(k_restage_half, dim3(1024), dim3(256), 0, ctx->stream, b.c1.w, d1, F, F, F, 32);     // k_conv3x3_h2: 32-channel stages
+            hipLaunchKernelGGL(k_restage_half, dim3(1024), dim3(256), 0, ctx->stream, b.c2.w, d2, F, F, F, 32);
             b.h1 = d1; b.h2 = d2;
         }
+        hipLaunchKernelGGL(k_restage_half, dim3(256), dim3(256), 0, ctx->stream, n->stem.w, n->stem_h, F, 16, 64, 32);
+        hipLaunchKernelGGL(k_restage_half, dim3(256), dim3(256), 0, ctx->stream, n->head.w, n->head_h, 16, F, F, 32);
         TG_HIP(ctx, hipGetLastError());
     } else if (n->dma) {
         // stage-ordered copy for k_conv3x3_sd: [slice*9 + tap][cout][16 channels of the slice]
@@ -1189,7 +1315,7 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
 void tg_net_destroy(tg_ctx* ctx) {
     if (!ctx || !ctx->eng || !ctx->eng->net) return;
     Net* n = ctx->eng->net;
-    void* ptrs[] = {n->blob, n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->bufQ, n->hca, n->bufAct, n->wstage, n->wh, n->act16, n->h16};
+    void* ptrs[] = {n->blob, n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->bufQ, n->hca, n->bufAct, n->wstage, n->wh, n->act16, n->h16, n->stem_h, n->head_h, n->x0h};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t ev : n->ev) (void)hipEventDestroy(ev);
     delete n;

@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void k_obs_to_rows(const float* __restrict__ o
 // Loads and stores retire through ONE in-order counter (vmcnt), so a load issued after stores waits for all of them: per-cout
 // parameters therefore come from LDS (par = bias | s2 | t2, COUT floats each), and the residual is fetched one 4-tile chunk
 // ahead of the stores of the previous chunk, which turns ~CT*NPT serialized memory round trips into counted, overlapped ones.
-// EPI 0: relu(acc + bias)   EPI 1: acc + bias + res   EPI 2: acc + bias;   out2 (optional) = relu(v * s2 + t2), stored as fp16 if H2.
-template <int COUT, int CT, int NPT, int EPI, bool H2 = false>
+// EPI 0: relu(acc + bias)   EPI 1: acc + bias + res   EPI 2: acc + bias;   out2 (optional) = relu(v * s2 + t2).
+template <int COUT, int CT, int NPT, int EPI>
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[CT][NPT], const int (&mrow)[NPT], int M, int co_base, int kq,
                                               float* __restrict__ out, const float* __restrict__ res, float* __restrict__ out2,
                                               const float* par) {
@@ -124,12 +124,6 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[CT][NPT], const int (
                     f32x4 u;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { float w = v[e] * sc[e] + sh[e]; u[e] = w > 0.f ? w : 0.f; }
-                    if (H2) {                                            // out2 is an fp16 tensor (first conv input of the fp16 chain)
-                        h4 uh;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) uh[e] = (_Float16)u[e];
-                        *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(out2) + (size_t)mrow[t] * COUT + co_base + col) = uh;
-                    } else
                     *reinterpret_cast<f32x4*>(out2 + (size_t)mrow[t] * COUT + co_base + col) = u;
                 }
             }
@@ -139,7 +133,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[CT][NPT], const int (
 
 // EPI 0: out = relu(acc + bias)      EPI 1: out = acc + bias + res      EPI 2: out = acc + bias
 // NTAP 9: 3x3 convolution with zero padding; NTAP 1: 1x1 convolution (the q/k/v projections of Self_Attention, model.py:294-296)
-template <int S, int CIN, int COUT, bool PRO, int EPI, int NTAP = 9, int NPT = 2, bool H2 = false>
+template <int S, int CIN, int COUT, bool PRO, int EPI, int NTAP = 9, int NPT = 2>
 // NPT = 3 only pays with two waves per SIMD (<= 256 registers, a handful of spills): measured 132 vs 118 TFLOP/s at one
 __global__ __launch_bounds__(256, (NPT > 2 ? 2 : 1)) void k_conv3x3(const float* __restrict__ in, float* __restrict__ out,
                                                  const float* __restrict__ res, const float* __restrict__ Wt,
@@ -280,7 +274,7 @@ __global__ __launch_bounds__(256, (NPT > 2 ? 2 : 1)) void k_conv3x3(const float*
     int mrow[NPT];
 #pragma unroll
     for (int t = 0; t < NPT; ++t) mrow[t] = m0 + (wave * NPT + t) * 16 + j;
-    conv_epilogue<COUT, CT, NPT, EPI, H2>(acc, mrow, M, 0, kq, out, res, out2, par);
+    conv_epilogue<COUT, CT, NPT, EPI>(acc, mrow, M, 0, kq, out, res, out2, par);
 }
 
 // LDS pointer type of the LDS-DMA builtins; counted wait on the in-order vector-memory counter (loads, stores and LDS-DMA share it)

@@ -775,6 +775,18 @@ __global__ __launch_bounds__(256) void k_restage_half(const float* __restrict__ 
     }
 }
 
+// stage-ordered f32 copy of an F->F conv for k_conv3x3_sd: dst[(slice*9 + tap)][cout][16] = w[tap][cout][slice*16 + c]
+__global__ __launch_bounds__(256) void k_restage_f32(const float* __restrict__ w, float* __restrict__ dst, int F) {
+    const size_t total = (size_t)9 * F * F;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i & 15);
+        const size_t r = i >> 4;
+        const int co = (int)(r % F);
+        const int st = (int)(r / F);
+        dst[i] = w[((size_t)(st % 9) * F + co) * F + (st / 9) * 16 + c];
+    }
+}
+
 // network input for the fp16 stem: obs f32 [rows][C][P] (planes of 0/1, exact in fp16) -> x0h [rows*P][64] halfs, channel-minor
 template <int S>
 __global__ __launch_bounds__(256) void k_obs_to_rows_h(const float* __restrict__ obs, _Float16* __restrict__ x0, int rows, int C) {
@@ -1284,23 +1296,15 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
         hipLaunchKernelGGL(k_restage_half, dim3(256), dim3(256), 0, ctx->stream, n->head.w, n->head_h, 16, F, F, 32);
         TG_HIP(ctx, hipGetLastError());
     } else if (n->dma) {
-        // stage-ordered copy for k_conv3x3_sd: [slice*9 + tap][cout][16 channels of the slice]
-        std::vector<float> sg(per * 2 * n->blocks.size());
-        auto restage = [&](const float* w, float* dst) {
-            for (int sl = 0; sl < F / 16; ++sl)
-                for (int tap = 0; tap < 9; ++tap)
-                    for (int co = 0; co < F; ++co)
-                        for (int c = 0; c < 16; ++c)
-                            dst[(((size_t)sl * 9 + tap) * F + co) * 16 + c] = w[((size_t)tap * F + co) * F + sl * 16 + c];
-        };
+        // stage-ordered copy for k_conv3x3_sd, [slice*9 + tap][cout][16 channels of the slice], made on the device
         for (size_t i = 0; i < n->blocks.size(); ++i) {
             BlockW& b = n->blocks[i];
-            restage(blob + (b.c1.w - n->blob), sg.data() + (2 * i) * per);
-            restage(blob + (b.c2.w - n->blob), sg.data() + (2 * i + 1) * per);
-            b.g1 = n->wstage + (2 * i) * per; b.g2 = n->wstage + (2 * i + 1) * per;
+            float* d1 = n->wstage + (2 * i) * per; float* d2 = n->wstage + (2 * i + 1) * per;
+            hipLaunchKernelGGL(k_restage_f32, dim3(1024), dim3(256), 0, ctx->stream, b.c1.w, d1, F);
+            hipLaunchKernelGGL(k_restage_f32, dim3(1024), dim3(256), 0, ctx->stream, b.c2.w, d2, F);
+            b.g1 = d1; b.g2 = d2;
         }
-        if (!sg.empty()) TG_HIP(ctx, hipMemcpyAsync(n->wstage, sg.data(), sizeof(float) * sg.size(), hipMemcpyHostToDevice, ctx->stream));
-        TG_HIP(ctx, hipStreamSynchronize(ctx->stream));           // sg is a local
+        TG_HIP(ctx, hipGetLastError());
     }
     TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return TG_OK;

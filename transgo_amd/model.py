@@ -35,6 +35,10 @@ def _np(t):
     return t.detach().cpu().numpy().astype(np.float64) if hasattr(t, "detach") else np.asarray(t, np.float64)
 
 
+def _np32(t):
+    return t.detach().cpu().numpy().astype(np.float32, copy=False) if hasattr(t, "detach") else np.asarray(t, np.float32)
+
+
 def _bn(sd, prefix):
     g, b = _np(sd[prefix + ".weight"]), _np(sd[prefix + ".bias"])
     m, v = _np(sd[prefix + ".running_mean"]), _np(sd[prefix + ".running_var"])
@@ -81,6 +85,7 @@ def pack_weights(sd, board_size, encode_dim, filters, blocks=None, prefix="main_
     P, A = S * S, S * S + 1
     out = []
     g = lambda k: _np(sd[prefix + k])
+    g32 = lambda k: _np32(sd[prefix + k])            # tensors that are copied unchanged skip the float64 round trip
 
     def attention(name):
         w = np.concatenate([g(name + f".{k}_conv.weight").reshape(-1, F) for k in ("query", "key", "value")], 0)
@@ -112,7 +117,7 @@ def pack_weights(sd, board_size, encode_dim, filters, blocks=None, prefix="main_
         s2, t2 = _bn(sd, prefix + pb + "batchnormlize_2")
         w1 = g(pb + "conv_1.weight") * s2[:, None, None, None]
         b1 = g(pb + "conv_1.bias") * s2 + t2
-        out += [s1, t1, _conv_t(w1), b1, _conv_t(g(pb + "conv_2.weight")), g(pb + "conv_2.bias")]
+        out += [s1, t1, _conv_t(w1), b1, _conv_t(g32(pb + "conv_2.weight")), g(pb + "conv_2.bias")]    # conv_2 is stored as is
     se, te = _bn(sd, prefix + "bn_res_end")
     out += [se, te]
     if arch.policy_attention:
@@ -123,7 +128,13 @@ def pack_weights(sd, board_size, encode_dim, filters, blocks=None, prefix="main_
         out += head_conv([("conv_val_own", 0, 2), ("conv_act", 2, 4)])
     out += [g("fc_val_own.weight").T, g("fc_val_own.bias"), g("fc_val.weight")[0], g("fc_val.bias"),
             g("fc_own.weight").T, g("fc_own.bias"), g("fc_act.weight").T, g("fc_act.bias")]
-    blob = np.concatenate([np.ascontiguousarray(a, np.float64).reshape(-1) for a in out]).astype(np.float32)
+    # folds are evaluated in float64 and rounded once, on the way into the float32 blob (assignment casts)
+    blob = np.empty(sum(int(np.size(a)) for a in out), np.float32)
+    o = 0
+    for a in out:
+        n = int(np.size(a))
+        blob[o:o + n] = np.asarray(a).reshape(-1)
+        o += n
     want = _lib.load().tg_net_blob_floats_arch(S, C, F, arch.code.encode())
     if blob.size != want:
         raise ValueError(f"packed {blob.size} floats, library expects {want} for S={S} C={C} F={F} arch={arch.code}")

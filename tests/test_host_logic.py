@@ -179,3 +179,34 @@ def test_packed_replay_file_roundtrip(tmp_path):
     assert n == a.index == b.index == 8 * 18
     for x, y in zip(a.data[:n], b.data[:n]):
         assert all(np.array_equal(p, q) for p, q in zip(x, y))
+
+
+def test_pack_weights_matches_a_float64_reference_fold():
+    """pack_weights writes straight into a float32 blob; the folded tensors must still be evaluated in float64 and rounded once
+    (the fp16 oracle emulation and the HIP path both assume exactly that), and unfolded tensors must be copied bit-for-bit."""
+    sd = model.random_weights(9, 10, 32, 2, seed=5)
+    blob = model.pack_weights(sd, 9, 10, 32, 2)
+    F = 32
+    p = "main_network.res_blocks.0."
+    s2 = sd[p + "batchnormlize_2.weight"].astype(np.float64) / np.sqrt(sd[p + "batchnormlize_2.running_var"].astype(np.float64) + 1e-5)
+    w1 = (sd[p + "conv_1.weight"].astype(np.float64) * s2[:, None, None, None]).reshape(F, F, 9).transpose(2, 0, 1).astype(np.float32)
+    o = 9 * F * 16 + F + 2 * F                                    # stem W, stem b, s1, t1
+    assert np.array_equal(blob[o:o + 9 * F * F], w1.reshape(-1))
+    o += 9 * F * F + F
+    w2 = sd[p + "conv_2.weight"].reshape(F, F, 9).transpose(2, 0, 1)
+    assert np.array_equal(blob[o:o + 9 * F * F], w2.reshape(-1))
+
+
+def test_bench_rooflines_are_computed_from_measured_inputs():
+    import bench
+    assert bench.flops_per_leaf(9, 10, 128, 6) == pytest.approx(289.7e6, rel=1e-3)             # SURVEY.md 8(d)
+    assert bench.flops_per_leaf(19, 10, 256, 20) == pytest.approx(17.06e9, rel=1e-3)
+    t = bench.tree_roofline(9, 10, sims=1000, evals=1000, depth_sum=2000, children_scored=160000, tree_ms=10.0, waves=5)
+    d, a = 2.0, 80.0
+    per_eval = 10 * 81 * 4 + 83 * 4 + a * 32 + 2 * 11
+    want = d * (a + 1) * 32 + 2 * (d + 1) * 32 + 96 + per_eval
+    assert t["bytes_per_sim"] == pytest.approx(want, abs=0.1) and t["mean_fanout"] == 80.0 and t["mean_depth"] == 2.0
+    assert t["achieved"] == pytest.approx(1000 * want / 10e-3 / 1e9, abs=0.06) and t["bound"] == "hbm"      # reported to 0.1 GB/s
+    assert bench.tree_roofline(9, 10, 0, 0, 0, 0, 0.0, 0) is None
+    assert "k_conv3x3_sd<9,128>" in bench.kernel_name(9, 128, "f32") and "k_conv3x3_h2<19,256>" in bench.kernel_name(19, 256, "f16")
+    assert bench.kernel_name(9, 64, "f32").startswith("k_conv3x3<9,64,64>")

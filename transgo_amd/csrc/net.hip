@@ -487,6 +487,11 @@ __global__ __launch_bounds__(256, sd_wg_per_cu(S, F)) void k_conv3x3_sd(const fl
 #ifndef TG_H2_GRID
 #define TG_H2_GRID 512       // multiple of 16
 #endif
+// fp16 activation tensors are SLICE-MAJOR: [channels/32][M rows][32 halfs], so the 16 rows x 64 B of a slab DMA piece are one
+// contiguous KB (8 full 128-B lines) instead of 16 half-used lines 2F bytes apart -- measured, a row-major slab piece costs the
+// texture-address path ~3x a contiguous weight piece.  Element (row m, channel c):
+__device__ __forceinline__ size_t h16_index(int m, int c, int M) { return ((size_t)(c >> 5) * M + m) * 32 + (c & 31); }
+
 // s_waitcnt vmcnt(n) for a wave-uniform n in [0, N]: the instruction takes an immediate
 template <int N>
 __device__ __forceinline__ void vmcnt_uniform(int n) {
@@ -524,7 +529,7 @@ __device__ __forceinline__ void conv_epilogue_h(f32x4 (&acc)[CT][NPT], const int
                 if (EPI == 0) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) u[e] = (_Float16)(v[e] > 0.f ? v[e] : 0.f);
-                    TG_NT_STORE(u, reinterpret_cast<h4*>(out16 + (size_t)mrow[t] * F + col));
+                    TG_NT_STORE(u, reinterpret_cast<h4*>(out16 + h16_index(mrow[t], col, M)));
                 } else {
                     if (EPI == 1) v = v + r[c & 1][i];
                     if (EPI == 4) {
@@ -537,7 +542,7 @@ __device__ __forceinline__ void conv_epilogue_h(f32x4 (&acc)[CT][NPT], const int
                         const f32x4 sh = *reinterpret_cast<const f32x4*>(par + 2 * pstride + lc);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { const float w = v[e] * sc[e] + sh[e]; u[e] = (_Float16)(w > 0.f ? w : 0.f); }
-                        TG_NT_STORE(u, reinterpret_cast<h4*>(out16 + (size_t)mrow[t] * F + col));
+                        TG_NT_STORE(u, reinterpret_cast<h4*>(out16 + h16_index(mrow[t], col, M)));
                     }
                 }
             }
@@ -591,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
     // a piece is 16 rows x 64 B: lane -> row prow, physical chunk pchk, which holds logical chunk pchk ^ swz64(row); pieces start at
     // multiples of 16 rows, so the lane's share of every source address is ONE register (the rest is wave-uniform)
     const int prow = lane / NCHK, pchk = lane % NCHK;
-    const int lane_x = (prow * CIN + (pchk ^ swz64(prow)) * 8) * 2;       // bytes, activation rows are CIN halfs apart
+    const int lane_x = (prow * KC + (pchk ^ swz64(prow)) * 8) * 2;        // bytes; slice-major input: rows of a slice are 64 B apart
     const int lane_w = prow * KC + (pchk ^ swz64(prow)) * 8;              // halfs, stage-tile rows are KC halfs apart
     auto dma_x = [&](int sl) {
 #pragma unroll
@@ -600,7 +605,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
             if (q < NXP) {                                               // wave-uniform
                 if (q * RPP + prow < NROW) {
                     // the whole offset must travel in voffset: soffset is not range-checked, and rows outside the tensor must read 0
-                    const int voff = ((m0 - HALO + q * RPP) * CIN + sl * KC) * 2 + lane_x;
+                    // rows before the tensor / past its end read 0 (bounds check); rows m < 0 or >= M of an inner slice read a
+                    // neighbouring slice's rows instead -- finite values that only masked taps could ever select
+                    const int voff = ((sl * M + m0 - HALO + q * RPP) * KC) * 2 + lane_x;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (tg_lds_void*)(&xs[sl & 1][q * 512]), 16, voff, 0, 0, 0);
                 }
             }
@@ -787,7 +794,7 @@ __global__ __launch_bounds__(256) void k_restage_f32(const float* __restrict__ w
     }
 }
 
-// network input for the fp16 stem: obs f32 [rows][C][P] (planes of 0/1, exact in fp16) -> x0h [rows*P][64] halfs, channel-minor
+// network input for the fp16 stem: obs f32 [rows][C][P] (planes of 0/1, exact in fp16) -> x0h, 64 channels, slice-major (h16_index)
 template <int S>
 __global__ __launch_bounds__(256) void k_obs_to_rows_h(const float* __restrict__ obs, _Float16* __restrict__ x0, int rows, int C) {
     constexpr int P = S * S;
@@ -797,7 +804,7 @@ __global__ __launch_bounds__(256) void k_obs_to_rows_h(const float* __restrict__
         const size_t m = i >> 6;
         const int p = (int)(m % P);
         const size_t r = m / P;
-        x0[i] = c < C ? (_Float16)obs[(r * C + c) * P + p] : (_Float16)0.f;
+        x0[h16_index((int)m, c, rows * P)] = c < C ? (_Float16)obs[(r * C + c) * P + p] : (_Float16)0.f;
     }
 }
 
@@ -820,14 +827,14 @@ __global__ __launch_bounds__(256, 2) void k_head_h(const _Float16* __restrict__ 
     if (tid < 4) zrow[tid] = 0.f;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in), 0, M * F * 2, 0x00020000);
     const int prow = lane / NCHK, pchk = lane % NCHK;
-    const int lane_x = (prow * F + (pchk ^ swz64(prow)) * 8) * 2;
+    const int lane_x = (prow * KC + (pchk ^ swz64(prow)) * 8) * 2;      // slice-major input (h16_index)
     const int lane_w = prow * KC + (pchk ^ swz64(prow)) * 8;
     auto dma = [&](int sl) {                                              // slab and weight block of slice sl
 #pragma unroll
         for (int i = 0; i < NXQ; ++i) {
             const int q = wave * NXQ + i;
             if (q < NXP && q * RPP + prow < NROW) {
-                const int voff = ((m0 - HALO + q * RPP) * F + sl * KC) * 2 + lane_x;
+                const int voff = ((sl * M + m0 - HALO + q * RPP) * KC) * 2 + lane_x;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (tg_lds_void*)(&xs[sl & 1][q * 512]), 16, voff, 0, 0, 0);
             }
         }

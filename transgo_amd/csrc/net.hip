@@ -84,7 +84,11 @@ __global__ __launch_bounds__(256) void k_obs_to_rows(const float* __restrict__ o
 // parameters therefore come from LDS (par = bias | s2 | t2, COUT floats each), and the residual is fetched one 4-tile chunk
 // ahead of the stores of the previous chunk, which turns ~CT*NPT serialized memory round trips into counted, overlapped ones.
 // EPI 0: relu(acc + bias)   EPI 1: acc + bias + res   EPI 2: acc + bias;   out2 (optional) = relu(v * s2 + t2).
-template <int COUT, int CT, int NPT, int EPI>
+// SM / SM2: `out` / `out2` is a SLICE-MAJOR f32 tensor [COUT/16][M][16] (f32_sm_index) -- the layout the DMA-fed kernel reads its
+// inputs in: a slab piece (16 rows x 64 B) is then one contiguous KB, and so is what one store instruction here writes.
+__device__ __forceinline__ size_t f32_sm_index(int m, int c, int M) { return ((size_t)(c >> 4) * M + m) * 16 + (c & 15); }
+
+template <int COUT, int CT, int NPT, int EPI, bool SM = false, bool SM2 = false>
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[CT][NPT], const int (&mrow)[NPT], int M, int co_base, int kq,
                                               float* __restrict__ out, const float* __restrict__ res, float* __restrict__ out2,
                                               const float* par) {
@@ -117,14 +121,14 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[CT][NPT], const int (
                 } else if (EPI == 1) {
                     v = v + r[c & 1][i];
                 }
-                *reinterpret_cast<f32x4*>(out + (size_t)mrow[t] * COUT + co_base + col) = v;
+                *reinterpret_cast<f32x4*>(out + (SM ? f32_sm_index(mrow[t], co_base + col, M) : (size_t)mrow[t] * COUT + co_base + col)) = v;
                 if (out2) {
                     const f32x4 sc = *reinterpret_cast<const f32x4*>(par + COUT + col);
                     const f32x4 sh = *reinterpret_cast<const f32x4*>(par + 2 * COUT + col);
                     f32x4 u;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { float w = v[e] * sc[e] + sh[e]; u[e] = w > 0.f ? w : 0.f; }
-                    *reinterpret_cast<f32x4*>(out2 + (size_t)mrow[t] * COUT + co_base + col) = u;
+                    *reinterpret_cast<f32x4*>(out2 + (SM2 ? f32_sm_index(mrow[t], co_base + col, M) : (size_t)mrow[t] * COUT + co_base + col)) = u;
                 }
             }
         }
@@ -133,7 +137,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[CT][NPT], const int (
 
 // EPI 0: out = relu(acc + bias)      EPI 1: out = acc + bias + res      EPI 2: out = acc + bias
 // NTAP 9: 3x3 convolution with zero padding; NTAP 1: 1x1 convolution (the q/k/v projections of Self_Attention, model.py:294-296)
-template <int S, int CIN, int COUT, bool PRO, int EPI, int NTAP = 9, int NPT = 2>
+template <int S, int CIN, int COUT, bool PRO, int EPI, int NTAP = 9, int NPT = 2, bool SM2 = false>
 // NPT = 3 only pays with two waves per SIMD (<= 256 registers, a handful of spills): measured 132 vs 118 TFLOP/s at one
 __global__ __launch_bounds__(256, (NPT > 2 ? 2 : 1)) void k_conv3x3(const float* __restrict__ in, float* __restrict__ out,
                                                  const float* __restrict__ res, const float* __restrict__ Wt,
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(256, (NPT > 2 ? 2 : 1)) void k_conv3x3(const float*
     int mrow[NPT];
 #pragma unroll
     for (int t = 0; t < NPT; ++t) mrow[t] = m0 + (wave * NPT + t) * 16 + j;
-    conv_epilogue<COUT, CT, NPT, EPI>(acc, mrow, M, 0, kq, out, res, out2, par);
+    conv_epilogue<COUT, CT, NPT, EPI, false, SM2>(acc, mrow, M, 0, kq, out, res, out2, par);
 }
 
 // LDS pointer type of the LDS-DMA builtins; counted wait on the in-order vector-memory counter (loads, stores and LDS-DMA share it)
@@ -345,7 +349,9 @@ __global__ __launch_bounds__(256, sd_wg_per_cu(S, F)) void k_conv3x3_sd(const fl
             if (q < NXP) {                                               // wave-uniform
                 const int r = q * 16 + prow;
                 if (r < NROW) {                                          // last piece: only the rows that exist
-                    const int voff = ((m0 - HALO + r) * F + sl * CC + pchunk * 4) * 4;           // outside the tensor: reads 0
+                    // slice-major input (f32_sm_index): the piece is one contiguous KB.  Before the tensor / past its end reads 0;
+                    // rows m < 0 or >= M of an inner slice read a neighbouring slice's rows, which only masked taps could select
+                    const int voff = ((sl * M + m0 - HALO + r) * CC + pchunk * 4) * 4;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (tg_lds_void*)(&xs[buf][q * 256]), 16, voff, 0, 0, 0);
                 }
             }
@@ -458,7 +464,8 @@ __global__ __launch_bounds__(256, sd_wg_per_cu(S, F)) void k_conv3x3_sd(const fl
     int mrow[NPT];
 #pragma unroll
     for (int t = 0; t < NPT; ++t) mrow[t] = m0 + (wave * NPT + t) * 16 + j;
-    conv_epilogue<F, CT, NPT, (EPI == 1 ? 2 : EPI)>(acc, mrow, M, 0, kq, out, res, out2, par);
+    // EPI 0 writes the next conv's input (slice-major); EPI 1 writes the row-major residual stream and, as out2, the next input
+    conv_epilogue<F, CT, NPT, (EPI == 1 ? 2 : EPI), EPI == 0, true>(acc, mrow, M, 0, kq, out, res, out2, par);
 #ifdef TG_SD_STAMP
     TG_STAMP(t_end);
     if (lane == 0) {
@@ -1068,9 +1075,9 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
             // prologue-free chain: every producer also writes relu(bn_next(.)) for its consumer
             const size_t nb = n->blocks.size();
             const float* s0 = nb ? n->blocks[0].s1 : n->s_end; const float* t0 = nb ? n->blocks[0].t1 : n->t_end;
-            hipLaunchKernelGGL((k_conv3x3<S, 16, F, false, 0>), dim3(grid), dim3(256), 0, st, (const float*)n->x0, x,
+            hipLaunchKernelGGL((k_conv3x3<S, 16, F, false, 0, 9, 2, true>), dim3(grid), dim3(256), 0, st, (const float*)n->x0, x,
                                (const float*)nullptr, n->stem.w, n->stem.b, (const float*)nullptr, (const float*)nullptr, M,
-                               n->bufAct, s0, t0);
+                               nb ? n->bufAct : (float*)nullptr, s0, t0);
             for (size_t i = 0; i < nb; ++i) {
                 const BlockW& b = n->blocks[i];
                 const float* sn = i + 1 < nb ? n->blocks[i + 1].s1 : n->s_end;
@@ -1082,11 +1089,12 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                                      (const float*)nullptr, b.g1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M); }
                 { ProfScope ps(n, st, conv_flops);
                   hipLaunchKernelGGL((k_conv3x3_sd<S, F, 1>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufH, y,
-                                     (const float*)x, b.g2, b.c2.b, n->bufAct, sn, tn, M); }
+                                     (const float*)x, b.g2, b.c2.b, i + 1 < nb ? n->bufAct : (float*)nullptr, sn, tn, M); }
                 float* t = x; x = y; y = t;
             }
-            hipLaunchKernelGGL((k_conv3x3<S, F, 16, false, 0>), dim3(grid), dim3(256), 0, st, (const float*)n->bufAct, n->hc,
-                               (const float*)nullptr, n->head.w, n->head.b, (const float*)nullptr, (const float*)nullptr, M);
+            // bufAct / bufH are slice-major; the head conv reads the row-major residual stream and activates it while staging
+            hipLaunchKernelGGL((k_conv3x3<S, F, 16, true, 0>), dim3(grid), dim3(256), 0, st, (const float*)x, n->hc,
+                               (const float*)nullptr, n->head.w, n->head.b, n->s_end, n->t_end, M);
             hipLaunchKernelGGL((k_heads<S>), dim3(rows), dim3(256), 0, st, (const float*)n->hc, (const float*)n->hc, n->w_vo, n->b_vo,
                                n->w_v, n->b_v, n->w_o, n->b_o, n->w_a, n->b_a, policy, value, own);
             TG_HIP(ctx, hipGetLastError());

@@ -543,7 +543,7 @@ __device__ __forceinline__ void conv_epilogue_h(f32x4 (&acc)[CT][NPT], const int
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                     }
-                    TG_NT_STORE(v, reinterpret_cast<f32x4*>(out32 + (size_t)mrow[t] * F + col));
+                    if (out32) TG_NT_STORE(v, reinterpret_cast<f32x4*>(out32 + (size_t)mrow[t] * F + col));   // null: the last block (only its activation feeds the head)
                     if (out16) {
                         const f32x4 sc = *reinterpret_cast<const f32x4*>(par + pstride + lc);
                         const f32x4 sh = *reinterpret_cast<const f32x4*>(par + 2 * pstride + lc);
@@ -1061,7 +1061,7 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                                      (float*)nullptr, n->h16, (const float*)nullptr, b.h1, b.c1.b, (const float*)nullptr, (const float*)nullptr, M, nblk_h2); }
                 { ProfScope ps(n, st, conv_flops);
                   hipLaunchKernelGGL((k_conv3x3_h2<S, F, F, 1>), dim3(grid_h2), dim3(256), 0, st, (const _Float16*)n->h16,
-                                     y, a16, (const float*)x, b.h2, b.c2.b, sn, tn, M, nblk_h2); }
+                                     last ? (float*)nullptr : y, a16, (const float*)x, b.h2, b.c2.b, sn, tn, M, nblk_h2); }
                 float* t = x; x = y; y = t;
             }
             hipLaunchKernelGGL((k_head_h<S, F>), dim3(grid_h), dim3(256), 0, st, (const _Float16*)n->act16, n->hc,

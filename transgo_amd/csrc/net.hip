@@ -285,6 +285,24 @@ __global__ __launch_bounds__(256, (NPT > 2 ? 2 : 1)) void k_conv3x3(const float*
 typedef __attribute__((address_space(3))) void tg_lds_void;
 #define TG_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
+// LDS-DMA pieces (64 lanes x 16 B -> 1 KB of LDS at `lds`, lane-linear) issued as INLINE ASSEMBLY on purpose.  Through the
+// builtins hipcc knows that LDS is being written asynchronously, cannot see that the kernels' own counted s_waitcnt + s_barrier
+// already order every fragment read behind the pieces it needs, and inserts `s_waitcnt vmcnt(0)` in front of the next ds_read --
+// which makes every wave wait for the pieces it has JUST issued (two stages of landing slack thrown away, once per stage).
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+__device__ __forceinline__ u32x4 tg_rsrc(const void* base, unsigned bytes) {       // raw buffer: stride 0, bounds check on the byte offset
+    const unsigned long long a = (unsigned long long)base;
+    return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ void tg_dma_global(const void* sbase /*wave-uniform*/, int voff_bytes, tg_lds_void* lds) {
+    const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)lds);     // wave-uniform by construction; makes it an SGPR
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(la), "v"(voff_bytes), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void tg_dma_buffer(u32x4 rsrc, int voff_bytes, tg_lds_void* lds) {    // out-of-range offsets write zeros
+    const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)lds);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(la), "v"(voff_bytes), "s"(rsrc) : "memory");
+}
+
 // XOR swizzle of the 16-B chunk index for LDS images with 64-byte rows read as MFMA fragments by ds_read_b128 (lane = (j, kq):
 // row base + j, chunk kq).  The instruction is served in four 16-lane groups, each holding all 16 values of j with kq = q0 for
 // j in {0-3, 12-15} and q0^1 for j in {4-11} (MI355X_MICROARCH.md, LDS table); the 16-B slot of a lane is (row%4)*4 + chunk, so the
@@ -340,7 +358,7 @@ __global__ __launch_bounds__(256, sd_wg_per_cu(S, F)) void k_conv3x3_sd(const fl
     if (tid < 4) *reinterpret_cast<f32x4*>(zrow + tid * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int i = tid; i < F; i += 256) { par[i] = bias[i]; par[F + i] = out2 ? s2[i] : 0.f; par[2 * F + i] = out2 ? t2[i] : 0.f; }
 
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, M * F * 4, 0x00020000);
+    const u32x4 rin = tg_rsrc(in, (unsigned)M * F * 4);
     const int prow = lane >> 2, pchunk = (lane & 3) ^ swz64(lane >> 2);      // row within a 16-row piece, swizzled source chunk
     auto dma_x = [&](int sl, int buf) {
 #pragma unroll
@@ -352,7 +370,7 @@ __global__ __launch_bounds__(256, sd_wg_per_cu(S, F)) void k_conv3x3_sd(const fl
                     // slice-major input (f32_sm_index): the piece is one contiguous KB.  Before the tensor / past its end reads 0;
                     // rows m < 0 or >= M of an inner slice read a neighbouring slice's rows, which only masked taps could select
                     const int voff = ((sl * M + m0 - HALO + r) * CC + pchunk * 4) * 4;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (tg_lds_void*)(&xs[buf][q * 256]), 16, voff, 0, 0, 0);
+                    tg_dma_buffer(rin, voff, (tg_lds_void*)(&xs[buf][q * 256]));
                 }
             }
         }
@@ -362,8 +380,7 @@ __global__ __launch_bounds__(256, sd_wg_per_cu(S, F)) void k_conv3x3_sd(const fl
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
             const int pc = wave * WPW + i;
-            __builtin_amdgcn_global_load_lds(Ws + (size_t)gg * (F * CC) + (pc * 16 + prow) * CC + pchunk * 4,
-                                             (tg_lds_void*)(&ws[g % D][pc * 256]), 16, 0, 0);
+            tg_dma_global(Ws + (size_t)gg * (F * CC) + pc * 16 * CC, (prow * CC + pchunk * 4) * 4, (tg_lds_void*)(&ws[g % D][pc * 256]));
         }
     };
     unsigned vmask[NPT]; int vrow[NPT];
@@ -494,6 +511,116 @@ __global__ __launch_bounds__(256, sd_wg_per_cu(S, F)) void k_conv3x3_sd(const fl
 #ifndef TG_H2_GRID
 #define TG_H2_GRID 512       // multiple of 16
 #endif
+// ---- slab-free variant of k_conv3x3_sd (TG_DMA_CONV=2) -----------------------------------------------------------------------
+// With slice-major inputs a B fragment (16 rows x 64 B of one 16-channel slice) is ONE contiguous KB in memory, so every wave
+// loads its own B fragments straight from L2 into registers (buffer loads, a stage ahead; out-of-board taps and rows outside the
+// batch get an out-of-range offset, i.e. zeros) and the LDS holds nothing but the weight ring.  That makes room for a
+// 6-slot ring at three workgroups per CU (F=128), i.e. ONE barrier per PAIR of stages, and removes the slab DMAs, the B
+// fragment LDS reads and the zero-row select.  Everything is at least one stage old when it is waited for, so each stage
+// simply ends with s_waitcnt vmcnt(0).
+template <int S, int F, int EPI>
+__global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sg(const float* __restrict__ in, float* __restrict__ out,
+                                                                       const float* __restrict__ res, const float* __restrict__ Ws,
+                                                                       const float* __restrict__ bias, float* __restrict__ out2,
+                                                                       const float* __restrict__ s2, const float* __restrict__ t2, int M) {
+    constexpr int P = S * S, CT = F / 16, CC = 16;
+    constexpr int NPT = F == 128 ? 3 : 2, TM = 64 * NPT;
+    constexpr int WPW = CT / 4;
+    constexpr int NSL = F / CC, NST = NSL * 9, NPAIR = NST / 2, D = F == 128 ? 6 : 4, NPF = D / 2;
+    static_assert((F == 128 || F == 256) && NST % 2 == 0, "tile geometry");
+    __shared__ __attribute__((aligned(16))) float ws[D][F * CC];
+    __shared__ __attribute__((aligned(16))) float par[3 * F];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * TM;
+    for (int i = tid; i < F; i += 256) { par[i] = bias[i]; par[F + i] = out2 ? s2[i] : 0.f; par[2 * F + i] = out2 ? t2[i] : 0.f; }
+
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, M * F * 4, 0x00020000);
+    const int prow = lane >> 2, pchunk = (lane & 3) ^ swz64(lane >> 2);
+    auto dma_w = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            const int pc = wave * WPW + i;
+            tg_dma_global(Ws + (size_t)g * (F * CC) + pc * 16 * CC, (prow * CC + pchunk * 4) * 4, (tg_lds_void*)(&ws[g % D][pc * 256]));
+        }
+    };
+    unsigned vmask[NPT]; int boff[NPT];
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) {
+        const int m = m0 + (wave * NPT + t) * 16 + j;
+        unsigned mk = 0;
+        if (m < M) {
+            const int p = m % P, x = p % S, y = p / S;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                if (yy >= 0 && yy < S && xx >= 0 && xx < S) mk |= 1u << tap;
+            }
+        }
+        vmask[t] = mk; boff[t] = (m * CC + kq * 4) * 4;                  // byte offset of this lane's 16 B inside slice 0
+    }
+    auto load_b = [&](f32x4* b, int g) {
+        const int sl = g / 9, tap = g % 9;
+        const int soff = (sl * M + (tap / 3 - 1) * S + (tap % 3 - 1)) * (CC * 4);       // wave-uniform: slice base + tap shift
+#pragma unroll
+        for (int t = 0; t < NPT; ++t) {
+            const int voff = ((vmask[t] >> tap) & 1) ? boff[t] + soff : 0x7ffffff0;    // masked: out of range = zeros
+            b[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, voff, 0, 0));
+        }
+    };
+    const int aoff = j * CC + ((kq ^ swz64(j)) << 2);
+    f32x4 acc[CT][NPT];
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) {
+        const int m = m0 + (wave * NPT + t) * 16 + j;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (EPI == 1 && m < M) acc[ct][t] = *reinterpret_cast<const f32x4*>(res + (size_t)m * F + ct * 16 + kq * 4);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) { dma_w(2 * q); dma_w(2 * q + 1); }
+    f32x4 b_cur[NPT], b_next[NPT];
+    load_b(b_cur, 0);
+    TG_VMCNT(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+#pragma unroll 1
+    for (int pp = 0; pp < NPAIR; ++pp) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int g = 2 * pp + h;
+            const float* wcur = ws[g % D];
+            if (g + 1 < NST) load_b(b_next, g + 1);
+            __builtin_amdgcn_sched_barrier(0);                           // keep the loads HERE: hipcc sinks them to their use, a stage later
+            f32x4 a_cur = *reinterpret_cast<const f32x4*>(wcur + aoff);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                f32x4 a_next = a_cur;
+                if (ct + 1 < CT) a_next = *reinterpret_cast<const f32x4*>(wcur + (ct + 1) * 256 + aoff);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int t = 0; t < NPT; ++t)
+                        acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s4], b_cur[t][s4], acc[ct][t], 0, 0, 0);
+                a_cur = a_next;
+            }
+            TG_VMCNT(0);                                                 // B fragments of stage g+1 (and any weight pieces): a stage old
+#pragma unroll
+            for (int t = 0; t < NPT; ++t) b_cur[t] = b_next[t];
+        }
+        __builtin_amdgcn_s_barrier();                                    // pair pp+1 has landed for everybody; the slots of pair pp are free
+        if (2 * (pp + NPF) < NST) { dma_w(2 * (pp + NPF)); dma_w(2 * (pp + NPF) + 1); }
+    }
+    int mrow[NPT];
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) mrow[t] = m0 + (wave * NPT + t) * 16 + j;
+    conv_epilogue<F, CT, NPT, (EPI == 1 ? 2 : EPI), EPI == 0, true>(acc, mrow, M, 0, kq, out, res, out2, par);
+}
+
 // fp16 activation tensors are SLICE-MAJOR: [channels/32][M rows][32 halfs], so the 16 rows x 64 B of a slab DMA piece are one
 // contiguous KB (8 full 128-B lines) instead of 16 half-used lines 2F bytes apart -- measured, a row-major slab piece costs the
 // texture-address path ~3x a contiguous weight piece.  Element (row m, channel c):
@@ -599,7 +726,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
     for (int i = tid; i < NCO; i += 256) {
         par[i] = bias[co0 + i]; par[NCO + i] = out16 && s2 ? s2[co0 + i] : 0.f; par[2 * NCO + i] = out16 && t2 ? t2[co0 + i] : 0.f;
     }
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in), 0, M * CIN * 2, 0x00020000);
+    const u32x4 rin = tg_rsrc(in, (unsigned)M * CIN * 2);
     // a piece is 16 rows x 64 B: lane -> row prow, physical chunk pchk, which holds logical chunk pchk ^ swz64(row); pieces start at
     // multiples of 16 rows, so the lane's share of every source address is ONE register (the rest is wave-uniform)
     const int prow = lane / NCHK, pchk = lane % NCHK;
@@ -615,7 +742,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
                     // rows before the tensor / past its end read 0 (bounds check); rows m < 0 or >= M of an inner slice read a
                     // neighbouring slice's rows instead -- finite values that only masked taps could ever select
                     const int voff = ((sl * M + m0 - HALO + q * RPP) * KC) * 2 + lane_x;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (tg_lds_void*)(&xs[sl & 1][q * 512]), 16, voff, 0, 0, 0);
+                    tg_dma_buffer(rin, voff, (tg_lds_void*)(&xs[sl & 1][q * 512]));
                 }
             }
         }
@@ -625,7 +752,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
         for (int i = 0; i < WPW; ++i) {
             const int pc = wave * WPW + i;
             const _Float16* wb = Ws + ((size_t)g * F + co0 + pc * RPP) * KC;                       // wave-uniform
-            __builtin_amdgcn_global_load_lds(wb + lane_w, (tg_lds_void*)(&ws[g % NSLOT][pc * 512]), 16, 0, 0);
+            tg_dma_global(wb, lane_w * 2, (tg_lds_void*)(&ws[g % NSLOT][pc * 512]));
         }
     };
     auto prologue = [&]() {                                              // order matters for the counted wait below
@@ -832,7 +959,7 @@ __global__ __launch_bounds__(256, 2) void k_head_h(const _Float16* __restrict__ 
     const int j = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.x * TM;
     if (tid < 4) zrow[tid] = 0.f;
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in), 0, M * F * 2, 0x00020000);
+    const u32x4 rin = tg_rsrc(in, (unsigned)M * F * 2);
     const int prow = lane / NCHK, pchk = lane % NCHK;
     const int lane_x = (prow * KC + (pchk ^ swz64(prow)) * 8) * 2;      // slice-major input (h16_index)
     const int lane_w = prow * KC + (pchk ^ swz64(prow)) * 8;
@@ -842,13 +969,13 @@ __global__ __launch_bounds__(256, 2) void k_head_h(const _Float16* __restrict__ 
             const int q = wave * NXQ + i;
             if (q < NXP && q * RPP + prow < NROW) {
                 const int voff = ((sl * M + m0 - HALO + q * RPP) * KC) * 2 + lane_x;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (tg_lds_void*)(&xs[sl & 1][q * 512]), 16, voff, 0, 0, 0);
+                tg_dma_buffer(rin, voff, (tg_lds_void*)(&xs[sl & 1][q * 512]));
             }
         }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
             if (tap % NW == wave)                                        // one 1-KB piece per tap: 16 couts x 32 channels
-                __builtin_amdgcn_global_load_lds(Wh + ((size_t)sl * 9 + tap) * 16 * KC + lane_w, (tg_lds_void*)(&wsl[sl & 1][tap * 512]), 16, 0, 0);
+                tg_dma_global(Wh + ((size_t)sl * 9 + tap) * 16 * KC, lane_w * 2, (tg_lds_void*)(&wsl[sl & 1][tap * 512]));
     };
     unsigned vmask[NPT]; int vrow[NPT];
 #pragma unroll
@@ -1084,12 +1211,22 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                 const float* tn = i + 1 < nb ? n->blocks[i + 1].t1 : n->t_end;
                 constexpr int SD_TM = F == 128 ? 192 : 128;
                 const int grid_sd = (M + SD_TM - 1) / SD_TM;
-                { ProfScope ps(n, st, conv_flops);
-                  hipLaunchKernelGGL((k_conv3x3_sd<S, F, 0>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufAct, n->bufH,
-                                     (const float*)nullptr, b.g1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M); }
-                { ProfScope ps(n, st, conv_flops);
-                  hipLaunchKernelGGL((k_conv3x3_sd<S, F, 1>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufH, y,
-                                     (const float*)x, b.g2, b.c2.b, i + 1 < nb ? n->bufAct : (float*)nullptr, sn, tn, M); }
+                float* const actn = i + 1 < nb ? n->bufAct : (float*)nullptr;
+                if (n->dma == 2) {
+                    { ProfScope ps(n, st, conv_flops);
+                      hipLaunchKernelGGL((k_conv3x3_sg<S, F, 0>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufAct, n->bufH,
+                                         (const float*)nullptr, b.g1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M); }
+                    { ProfScope ps(n, st, conv_flops);
+                      hipLaunchKernelGGL((k_conv3x3_sg<S, F, 1>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufH, y,
+                                         (const float*)x, b.g2, b.c2.b, actn, sn, tn, M); }
+                } else {
+                    { ProfScope ps(n, st, conv_flops);
+                      hipLaunchKernelGGL((k_conv3x3_sd<S, F, 0>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufAct, n->bufH,
+                                         (const float*)nullptr, b.g1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M); }
+                    { ProfScope ps(n, st, conv_flops);
+                      hipLaunchKernelGGL((k_conv3x3_sd<S, F, 1>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufH, y,
+                                         (const float*)x, b.g2, b.c2.b, actn, sn, tn, M); }
+                }
                 float* t = x; x = y; y = t;
             }
             // bufAct / bufH are slice-major; the head conv reads the row-major residual stream and activates it while staging
@@ -1247,7 +1384,7 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
 
         if (any_att) TG_HIP(ctx, hipMalloc((void**)&n->bufQ, sizeof(float) * (size_t)rows_cap * P * Wq));
         if (pol) TG_HIP(ctx, hipMalloc((void**)&n->hca, sizeof(float) * (size_t)rows_cap * P * 16));
-        n->dma = (!any_att && (F == 128 || F == 256)) ? (getenv("TG_DMA_CONV") ? (atoi(getenv("TG_DMA_CONV")) != 0) : 1) : 0;
+        n->dma = (!any_att && (F == 128 || F == 256)) ? (getenv("TG_DMA_CONV") ? atoi(getenv("TG_DMA_CONV")) : 1) : 0;
         if (prec == 1) n->dma = 0;
         const size_t wcopy = (size_t)(NB > 0 ? 2 * NB : 1) * 9 * F * F;
         if (n->dma) TG_HIP(ctx, hipMalloc((void**)&n->wstage, sizeof(float) * wcopy));

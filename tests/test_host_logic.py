@@ -208,5 +208,5 @@ def test_bench_rooflines_are_computed_from_measured_inputs():
     assert t["bytes_per_sim"] == pytest.approx(want, abs=0.1) and t["mean_fanout"] == 80.0 and t["mean_depth"] == 2.0
     assert t["achieved"] == pytest.approx(1000 * want / 10e-3 / 1e9, abs=0.06) and t["bound"] == "hbm"      # reported to 0.1 GB/s
     assert bench.tree_roofline(9, 10, 0, 0, 0, 0, 0.0, 0) is None
-    assert "k_conv3x3_sd<9,128>" in bench.kernel_name(9, 128, "f32") and "k_conv3x3_h2<19,256>" in bench.kernel_name(19, 256, "f16")
+    assert "k_conv3x3_sg<9,128>" in bench.kernel_name(9, 128, "f32") and "k_conv3x3_h2<19,256>" in bench.kernel_name(19, 256, "f16")
     assert bench.kernel_name(9, 64, "f32").startswith("k_conv3x3<9,64,64>")

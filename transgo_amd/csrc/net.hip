@@ -34,7 +34,7 @@ struct Layer { int kind; int ridx; AttW a; };                                   
 struct Net {
     int F = 0, NB = 0, C = 0, S = 0, P = 0, A = 0;
     float* blob = nullptr; size_t blob_floats = 0;
-    float* wstage = nullptr; // [2*NB][F/16*9][F][16] stage-ordered F->F conv weights (k_conv3x3_sd)
+    float* wstage = nullptr; // [2*NB][F/16*9][F][16] stage-ordered F->F conv weights (k_conv3x3_sg)
     ConvW stem; std::vector<BlockW> blocks; std::vector<Layer> layers; const float* s_end = nullptr; const float* t_end = nullptr;
     bool pol_att = false; AttW patt; ConvW head_a; std::string arch;
     float* bufQ = nullptr; float* hca = nullptr;   // q|k|v projections [rows][P][1.5F]; policy head conv output
@@ -42,7 +42,7 @@ struct Net {
     int prec = 0;                                  // cfg.net_precision: 0 = f32, 1 = fp16 storage + f32 accumulate (k_conv3x3_h)
     _Float16* stem_h = nullptr; _Float16* head_h = nullptr; _Float16* x0h = nullptr;   // fp16 path: stem [2*9][F][32] (16 planes padded to 64), head [F/32*9][16][32], input [rows][P][64]
     _Float16* wh = nullptr; _Float16* act16 = nullptr; _Float16* h16 = nullptr;   // fp16 path: weights [2*NB][F/32*9][F][32], activations [rows][P][F]
-    int dma = 0;                                   // attention-free F=128/256 f32 tower: 1 = k_conv3x3_sd chain (default), 0 = k_conv3x3 (TG_DMA_CONV=0)
+    int dma = 0;                                   // attention-free F=128/256 f32 tower: 1 = k_conv3x3_sg chain (default), 0 = k_conv3x3 (TG_DMA_CONV=0)
     ConvW head; const float* w_vo = nullptr; const float* b_vo = nullptr; const float* w_v = nullptr; const float* b_v = nullptr;
     const float* w_o = nullptr; const float* b_o = nullptr; const float* w_a = nullptr; const float* b_a = nullptr;
     float* x0 = nullptr;   // [rows][P][16] input planes, channel-minor
@@ -315,189 +315,6 @@ __device__ __forceinline__ int swz64(int row) { return ((row >> 2) & 1) << 1; }
 __device__ unsigned long long tg_sd_dbg[8];          // diagnostic build only: summed cycles per phase, all waves
 #define TG_STAMP(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory")
 #endif
-// ---- shared-tile LDS-DMA 3x3 conv (F = 128 / 256, attention-free tower; input already activated by its producer) ----------------
-// F = 128: workgroup = 4 waves = 192 consecutive rows x all 128 output channels (wave: 3 position tiles x 8 cout tiles, 96
-// accumulator registers) -- small enough in registers (<= 168) and LDS (52.8 KB) for THREE workgroups per CU, i.e. three waves
-// per SIMD to fill each other's bubbles, and at 16384 leaves the 6912 workgroups are exactly 9 rounds of the 768 resident slots.
-// F = 256: 128 rows x 256 channels (2 x 16 tiles, 128 accumulators), two workgroups per CU.
-// Stage g = (16-channel slice, tap): its 8-KB weight tile arrives by global_load_lds from a stage-ordered copy of the weights
-// ([slice*9+tap][cout][16]) into a 3-deep LDS ring, two stages ahead of use; the activation slab of the NEXT slice arrives by
-// buffer_load..lds (bounds check = zero fill) into the other of two slab buffers while taps 5-8 of the current one run.
-// The LDS image is XOR-swizzled at the SOURCE (a 64-B row keeps chunk c at position c ^ swz64(row); DMA destinations must
-// stay lane-linear); see swz64 for why that XOR makes every ds_read_b128 fragment read conflict-free.  One raw s_barrier per stage,
-// preceded by a counted vmcnt wait for the wave's own pieces of the next stage (DMAs retire in issue order).
-// workgroups per CU of k_conv3x3_sd: three if its LDS (two slabs, 3-slot weight ring, epilogue parameters, zero row) fits three times
-constexpr int sd_wg_per_cu(int S, int F) {
-    const int npt = F == 128 ? 3 : 2, nrow = 64 * npt + 2 * (S + 1);
-    const int lds = (2 * nrow * 16 + 3 * F * 16 + 3 * F + 16) * 4;
-    return F == 128 && 3 * lds <= 160 * 1024 ? 3 : 2;
-}
-
-template <int S, int F, int EPI>
-__global__ __launch_bounds__(256, sd_wg_per_cu(S, F)) void k_conv3x3_sd(const float* __restrict__ in, float* __restrict__ out,
-                                                       const float* __restrict__ res, const float* __restrict__ Ws,
-                                                       const float* __restrict__ bias, float* __restrict__ out2,
-                                                       const float* __restrict__ s2, const float* __restrict__ t2, int M) {
-    constexpr int P = S * S, HALO = S + 1, CT = F / 16, CC = 16;
-    constexpr int NPT = F == 128 ? 3 : 2, TM = 64 * NPT;        // accumulators: CT*NPT*4 = 96 (F=128) / 128 (F=256) registers
-    constexpr int WPW = CT / 4;                                  // weight pieces (16 couts x 16 channels) per wave per stage
-    constexpr int NSL = F / CC, NST = NSL * 9, D = 3;
-    constexpr int NROW = TM + 2 * HALO;               // slab rows actually needed
-    constexpr int NXP = (NROW + 15) / 16;             // DMA pieces per slab (the last one partially masked)
-    constexpr int NXQ = (NXP + 3) / 4;                // pieces issued by waves 0-2
-    constexpr int NX3 = NXP - 3 * NXQ;                // pieces issued by wave 3
-    static_assert((F == 128 || F == 256) && NX3 > 0 && NX3 <= NXQ, "tile geometry");
-    __shared__ __attribute__((aligned(16))) float xs[2][NROW * CC];
-    __shared__ __attribute__((aligned(16))) float ws[D][F * CC];
-    __shared__ __attribute__((aligned(16))) float par[3 * F];
-    __shared__ __attribute__((aligned(16))) float zrow[CC];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably wave-uniform (selects wait immediates)
-    const int j = lane & 15, kq = lane >> 4;
-    const int m0 = blockIdx.x * TM;
-    if (tid < 4) *reinterpret_cast<f32x4*>(zrow + tid * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int i = tid; i < F; i += 256) { par[i] = bias[i]; par[F + i] = out2 ? s2[i] : 0.f; par[2 * F + i] = out2 ? t2[i] : 0.f; }
-
-    const u32x4 rin = tg_rsrc(in, (unsigned)M * F * 4);
-    const int prow = lane >> 2, pchunk = (lane & 3) ^ swz64(lane >> 2);      // row within a 16-row piece, swizzled source chunk
-    auto dma_x = [&](int sl, int buf) {
-#pragma unroll
-        for (int i = 0; i < NXQ; ++i) {
-            const int q = wave * NXQ + i;
-            if (q < NXP) {                                               // wave-uniform
-                const int r = q * 16 + prow;
-                if (r < NROW) {                                          // last piece: only the rows that exist
-                    // slice-major input (f32_sm_index): the piece is one contiguous KB.  Before the tensor / past its end reads 0;
-                    // rows m < 0 or >= M of an inner slice read a neighbouring slice's rows, which only masked taps could select
-                    const int voff = ((sl * M + m0 - HALO + r) * CC + pchunk * 4) * 4;
-                    tg_dma_buffer(rin, voff, (tg_lds_void*)(&xs[buf][q * 256]));
-                }
-            }
-        }
-    };
-    auto dma_w = [&](int g) {
-        const int gg = g < NST ? g : NST - 1;
-#pragma unroll
-        for (int i = 0; i < WPW; ++i) {
-            const int pc = wave * WPW + i;
-            tg_dma_global(Ws + (size_t)gg * (F * CC) + pc * 16 * CC, (prow * CC + pchunk * 4) * 4, (tg_lds_void*)(&ws[g % D][pc * 256]));
-        }
-    };
-    unsigned vmask[NPT]; int vrow[NPT];
-#pragma unroll
-    for (int t = 0; t < NPT; ++t) {
-        const int m = m0 + (wave * NPT + t) * 16 + j;
-        unsigned mk = 0;
-        if (m < M) {
-            const int p = m % P, x = p % S, y = p / S;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-                if (yy >= 0 && yy < S && xx >= 0 && xx < S) mk |= 1u << tap;
-            }
-        }
-        vmask[t] = mk; vrow[t] = (wave * NPT + t) * 16 + j + HALO;
-    }
-    const int aoff = j * CC + ((kq ^ swz64(j)) << 2);             // A fragment: row ct*16+j of the stage tile
-    auto read_b = [&](f32x4* b, int g) {
-        const int sl = g / 9, tap = g % 9;
-        const int toff = (tap / 3 - 1) * S + (tap % 3 - 1);
-        const float* base = xs[sl & 1];
-#pragma unroll
-        for (int t = 0; t < NPT; ++t) {
-            const int R = vrow[t] + toff;
-            const float* src = ((vmask[t] >> tap) & 1) ? base + R * CC + ((kq ^ swz64(R)) << 2) : zrow + kq * 4;
-            b[t] = *reinterpret_cast<const f32x4*>(src);
-        }
-    };
-    // EPI 1: the accumulators START from the residual -- CT*NPT loads per wave that fly while the first DMAs land (they are older
-    // than the DMAs, so the counted wait below covers them) -- and the epilogue has no load behind its stores
-    f32x4 acc[CT][NPT];
-#pragma unroll
-    for (int t = 0; t < NPT; ++t) {
-        const int m = m0 + (wave * NPT + t) * 16 + j;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (EPI == 1 && m < M) acc[ct][t] = *reinterpret_cast<const f32x4*>(res + (size_t)m * F + ct * 16 + kq * 4);
-        }
-    }
-
-#ifdef TG_SD_STAMP
-    unsigned long long t_start, t_pro, t_a, t_b, t_c, t_loop, t_end, s_dma = 0, s_bar = 0;
-    TG_STAMP(t_start);
-#endif
-    dma_x(0, 0); dma_w(0); dma_w(1);
-    TG_VMCNT(WPW);                                    // own pieces of X(0) and W(0) landed (W(1) may be in flight)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // own ds_writes (zero row, epilogue parameters) retired
-    __builtin_amdgcn_s_barrier();                     // ... and everybody else's: stage 0 is visible
-#ifdef TG_SD_STAMP
-    TG_STAMP(t_pro);
-#endif
-    f32x4 b_cur[NPT], b_next[NPT];
-    read_b(b_cur, 0);
-
-    for (int g = 0; g < NST; ++g) {
-        const float* wcur = ws[g % D];
-        const int tap = g % 9;
-        const bool more = g / 9 + 1 < NSL;
-        f32x4 a_cur = *reinterpret_cast<const f32x4*>(wcur + aoff);
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            f32x4 a_next = a_cur;
-            if (ct + 1 < CT) a_next = *reinterpret_cast<const f32x4*>(wcur + (ct + 1) * 256 + aoff);
-            if (ct == 4 && g + 1 < NST) read_b(b_next, g + 1);           // the slab of stage g+1 is visible (same slice, or landed by tap 6)
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                for (int t = 0; t < NPT; ++t)
-                    acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s4], b_cur[t][s4], acc[ct][t], 0, 0, 0);
-            a_cur = a_next;
-        }
-#pragma unroll
-        for (int t = 0; t < NPT; ++t) b_cur[t] = b_next[t];
-        // slot (g+2)%D held stage g-1, which every wave left before the barrier that ended it
-        dma_w(g + 2);
-        if (more && tap == 4) dma_x(g / 9 + 1, (g / 9 + 1) & 1);
-        // own pieces of W(g+1) landed?  Younger: W(g+2) (WPW pieces) and, at taps 4-5, this wave's slab pieces issued after it
-#ifdef TG_SD_STAMP
-        TG_STAMP(t_a);
-#endif
-        if (more && (tap == 4 || tap == 5)) { if (wave == 3) TG_VMCNT(WPW + NX3); else TG_VMCNT(WPW + NXQ); }
-        else TG_VMCNT(WPW);
-#ifdef TG_SD_STAMP
-        TG_STAMP(t_b);
-#endif
-        __builtin_amdgcn_s_barrier();
-#ifdef TG_SD_STAMP
-        TG_STAMP(t_c);
-        s_dma += t_b - t_a; s_bar += t_c - t_b;
-#endif
-    }
-#ifdef TG_SD_STAMP
-    TG_STAMP(t_loop);
-#endif
-    TG_VMCNT(0);                                      // no DMA may outlive the workgroup's LDS
-    int mrow[NPT];
-#pragma unroll
-    for (int t = 0; t < NPT; ++t) mrow[t] = m0 + (wave * NPT + t) * 16 + j;
-    // EPI 0 writes the next conv's input (slice-major); EPI 1 writes the row-major residual stream and, as out2, the next input
-    conv_epilogue<F, CT, NPT, (EPI == 1 ? 2 : EPI), EPI == 0, true>(acc, mrow, M, 0, kq, out, res, out2, par);
-#ifdef TG_SD_STAMP
-    TG_STAMP(t_end);
-    if (lane == 0) {
-        atomicAdd(&tg_sd_dbg[0], t_pro - t_start); atomicAdd(&tg_sd_dbg[1], s_dma); atomicAdd(&tg_sd_dbg[2], s_bar);
-        atomicAdd(&tg_sd_dbg[3], t_loop - t_pro); atomicAdd(&tg_sd_dbg[4], t_end - t_loop); atomicAdd(&tg_sd_dbg[5], 1ull);
-    }
-#endif
-}
-
-// ---- fp16-storage 3x3 conv (BASELINE config 5: "fp16 policy/value inference"; f32 accumulate) ---------------------------------
-// Activations and weights are _Float16 in HBM and LDS, products accumulate in f32 on v_mfma_f32_16x16x32_f16 (16x the f32 MFMA
-// rate), so the kernel is shaped by what feeds the pipe rather than by the pipe; see k_conv3x3_h2 below.
-// EPI 0: out16 = half(relu(acc + bias))     EPI 1: out32 = acc + bias + res ; out16 = half(relu(out32 * s2 + t2)) (optional)
-// EPI 2: as EPI 1 with the residual already inside acc (k_conv3x3_h2 starts its accumulators from it)
-// EPI 4 (stem): out32 = relu(acc + bias) ; out16 = half(relu(out32 * s2 + t2))
 #ifndef TG_H_DA
 #define TG_H_DA 4
 #endif
@@ -508,16 +325,25 @@ __global__ __launch_bounds__(256, sd_wg_per_cu(S, F)) void k_conv3x3_sd(const fl
 #define TG_NT_STORE(v, p) (*(p) = (v))          // measured: nontemporal stores/loads here are 7 % SLOWER (0.88 vs 0.82 ms per launch)
 #define TG_NT_LOAD(p) (*(p))
 #endif
+#ifndef TG_SG_NG
+#define TG_SG_NG 2           // k_conv3x3_sg at F=128: stages per barrier (ring = 2*NG slots of 8 KB); measured 2: 138.5, 3: 131.6, 4: 127.1 TFLOP/s
+#endif
 #ifndef TG_H2_GRID
 #define TG_H2_GRID 512       // multiple of 16
 #endif
-// ---- slab-free variant of k_conv3x3_sd (TG_DMA_CONV=2) -----------------------------------------------------------------------
-// With slice-major inputs a B fragment (16 rows x 64 B of one 16-channel slice) is ONE contiguous KB in memory, so every wave
-// loads its own B fragments straight from L2 into registers (buffer loads, a stage ahead; out-of-board taps and rows outside the
-// batch get an out-of-range offset, i.e. zeros) and the LDS holds nothing but the weight ring.  That makes room for a
-// 6-slot ring at three workgroups per CU (F=128), i.e. ONE barrier per PAIR of stages, and removes the slab DMAs, the B
-// fragment LDS reads and the zero-row select.  Everything is at least one stage old when it is waited for, so each stage
-// simply ends with s_waitcnt vmcnt(0).
+// ---- F->F 3x3 conv of the f32 tower (F = 128 / 256, attention-free; input already activated by its producer) -------------------
+// Implicit GEMM on v_mfma_f32_16x16x4_f32: D[cout][pos] += W[tap][cout][cin] * X[pos + tap][cin].  F = 128: workgroup = 4 waves =
+// 192 consecutive rows x all 128 couts (wave: 3 position x 8 cout tiles, 96 accumulator registers), <= 162 VGPRs and 34 KB of LDS,
+// so THREE workgroups share a CU (three waves per SIMD fill each other's bubbles) and 16384 leaves are exactly 9 rounds of the 768
+// resident slots.  F = 256: 128 rows x 256 couts (2 x 16 tiles), two workgroups per CU.
+// Stage g = (16-channel slice, tap).  A (weights): the stage's tile arrives by LDS-DMA from a stage-ordered copy of the weights
+// ([slice*9+tap][cout][16]) into a 4-slot ring, two stages per barrier, the next pair landing while this one is used; the LDS
+// image is XOR-swizzled at the source (swz64) so ds_read_b128 fragments are conflict-free.  B (activations): inputs are
+// slice-major, so a B fragment (16 rows x 64 B of one slice) is ONE contiguous KB in memory and every wave loads its own B
+// fragments straight from L2 into registers, a stage ahead (out-of-board taps and rows outside the batch get an out-of-range
+// buffer offset, i.e. zeros) -- no activation slab in LDS, no zero-row select.  Everything is at least a stage old when it is
+// waited for, so each stage simply ends with s_waitcnt vmcnt(0).  An earlier design staged the activations as LDS slabs
+// (k_conv3x3_sd, one barrier per stage, 53 KB): 1-3.5 % slower on every shape, removed.
 template <int S, int F, int EPI>
 __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sg(const float* __restrict__ in, float* __restrict__ out,
                                                                        const float* __restrict__ res, const float* __restrict__ Ws,
@@ -526,8 +352,8 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sg(const fl
     constexpr int P = S * S, CT = F / 16, CC = 16;
     constexpr int NPT = F == 128 ? 3 : 2, TM = 64 * NPT;
     constexpr int WPW = CT / 4;
-    constexpr int NSL = F / CC, NST = NSL * 9, NPAIR = NST / 2, D = F == 128 ? 6 : 4, NPF = D / 2;
-    static_assert((F == 128 || F == 256) && NST % 2 == 0, "tile geometry");
+    constexpr int NSL = F / CC, NST = NSL * 9, NG = TG_SG_NG, D = F == 128 ? 2 * NG : 4, NGS = D / 2, NGRP = NST / NGS;   // NGS stages per barrier, two groups resident
+    static_assert((F == 128 || F == 256) && NST % NGS == 0, "tile geometry");
     __shared__ __attribute__((aligned(16))) float ws[D][F * CC];
     __shared__ __attribute__((aligned(16))) float par[3 * F];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -581,7 +407,7 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sg(const fl
         }
     }
 #pragma unroll
-    for (int q = 0; q < NPF; ++q) { dma_w(2 * q); dma_w(2 * q + 1); }
+    for (int g = 0; g < D; ++g) dma_w(g);
     f32x4 b_cur[NPT], b_next[NPT];
     load_b(b_cur, 0);
     TG_VMCNT(0);
@@ -589,10 +415,10 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sg(const fl
     __builtin_amdgcn_s_barrier();
 
 #pragma unroll 1
-    for (int pp = 0; pp < NPAIR; ++pp) {
+    for (int pp = 0; pp < NGRP; ++pp) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int g = 2 * pp + h;
+        for (int h = 0; h < NGS; ++h) {
+            const int g = NGS * pp + h;
             const float* wcur = ws[g % D];
             if (g + 1 < NST) load_b(b_next, g + 1);
             __builtin_amdgcn_sched_barrier(0);                           // keep the loads HERE: hipcc sinks them to their use, a stage later
@@ -612,8 +438,11 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sg(const fl
 #pragma unroll
             for (int t = 0; t < NPT; ++t) b_cur[t] = b_next[t];
         }
-        __builtin_amdgcn_s_barrier();                                    // pair pp+1 has landed for everybody; the slots of pair pp are free
-        if (2 * (pp + NPF) < NST) { dma_w(2 * (pp + NPF)); dma_w(2 * (pp + NPF) + 1); }
+        __builtin_amdgcn_s_barrier();                                    // group pp+1 has landed for everybody; the slots of group pp are free
+        if (NGS * (pp + 2) < NST) {
+#pragma unroll
+            for (int h = 0; h < NGS; ++h) dma_w(NGS * (pp + 2) + h);
+        }
     }
     int mrow[NPT];
 #pragma unroll
@@ -916,7 +745,7 @@ __global__ __launch_bounds__(256) void k_restage_half(const float* __restrict__ 
     }
 }
 
-// stage-ordered f32 copy of an F->F conv for k_conv3x3_sd: dst[(slice*9 + tap)][cout][16] = w[tap][cout][slice*16 + c]
+// stage-ordered f32 copy of an F->F conv for k_conv3x3_sg: dst[(slice*9 + tap)][cout][16] = w[tap][cout][slice*16 + c]
 __global__ __launch_bounds__(256) void k_restage_f32(const float* __restrict__ w, float* __restrict__ dst, int F) {
     const size_t total = (size_t)9 * F * F;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -1212,21 +1041,12 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                 constexpr int SD_TM = F == 128 ? 192 : 128;
                 const int grid_sd = (M + SD_TM - 1) / SD_TM;
                 float* const actn = i + 1 < nb ? n->bufAct : (float*)nullptr;
-                if (n->dma == 2) {
-                    { ProfScope ps(n, st, conv_flops);
-                      hipLaunchKernelGGL((k_conv3x3_sg<S, F, 0>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufAct, n->bufH,
-                                         (const float*)nullptr, b.g1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M); }
-                    { ProfScope ps(n, st, conv_flops);
-                      hipLaunchKernelGGL((k_conv3x3_sg<S, F, 1>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufH, y,
-                                         (const float*)x, b.g2, b.c2.b, actn, sn, tn, M); }
-                } else {
-                    { ProfScope ps(n, st, conv_flops);
-                      hipLaunchKernelGGL((k_conv3x3_sd<S, F, 0>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufAct, n->bufH,
-                                         (const float*)nullptr, b.g1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M); }
-                    { ProfScope ps(n, st, conv_flops);
-                      hipLaunchKernelGGL((k_conv3x3_sd<S, F, 1>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufH, y,
-                                         (const float*)x, b.g2, b.c2.b, actn, sn, tn, M); }
-                }
+                { ProfScope ps(n, st, conv_flops);
+                  hipLaunchKernelGGL((k_conv3x3_sg<S, F, 0>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufAct, n->bufH,
+                                     (const float*)nullptr, b.g1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M); }
+                { ProfScope ps(n, st, conv_flops);
+                  hipLaunchKernelGGL((k_conv3x3_sg<S, F, 1>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufH, y,
+                                     (const float*)x, b.g2, b.c2.b, actn, sn, tn, M); }
                 float* t = x; x = y; y = t;
             }
             // bufAct / bufH are slice-major; the head conv reads the row-major residual stream and activates it while staging
@@ -1384,7 +1204,7 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
 
         if (any_att) TG_HIP(ctx, hipMalloc((void**)&n->bufQ, sizeof(float) * (size_t)rows_cap * P * Wq));
         if (pol) TG_HIP(ctx, hipMalloc((void**)&n->hca, sizeof(float) * (size_t)rows_cap * P * 16));
-        n->dma = (!any_att && (F == 128 || F == 256)) ? (getenv("TG_DMA_CONV") ? atoi(getenv("TG_DMA_CONV")) : 1) : 0;
+        n->dma = (!any_att && (F == 128 || F == 256)) ? (getenv("TG_DMA_CONV") ? (atoi(getenv("TG_DMA_CONV")) != 0) : 1) : 0;
         if (prec == 1) n->dma = 0;
         const size_t wcopy = (size_t)(NB > 0 ? 2 * NB : 1) * 9 * F * F;
         if (n->dma) TG_HIP(ctx, hipMalloc((void**)&n->wstage, sizeof(float) * wcopy));
@@ -1448,7 +1268,7 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
         hipLaunchKernelGGL(k_restage_half, dim3(256), dim3(256), 0, ctx->stream, n->head.w, n->head_h, 16, F, F, 32);
         TG_HIP(ctx, hipGetLastError());
     } else if (n->dma) {
-        // stage-ordered copy for k_conv3x3_sd, [slice*9 + tap][cout][16 channels of the slice], made on the device
+        // stage-ordered copy for k_conv3x3_sg, [slice*9 + tap][cout][16 channels of the slice], made on the device
         for (size_t i = 0; i < n->blocks.size(); ++i) {
             BlockW& b = n->blocks[i];
             float* d1 = n->wstage + (2 * i) * per; float* d2 = n->wstage + (2 * i + 1) * per;

@@ -328,9 +328,6 @@ __device__ unsigned long long tg_sd_dbg[8];          // diagnostic build only: s
 #ifndef TG_SG_NG
 #define TG_SG_NG 2           // k_conv3x3_sg at F=128: stages per barrier (ring = 2*NG slots of 8 KB); measured 2: 138.5, 3: 131.6, 4: 127.1 TFLOP/s
 #endif
-#ifndef TG_H2_GRID
-#define TG_H2_GRID 512       // multiple of 16
-#endif
 // ---- F->F 3x3 conv of the f32 tower (F = 128 / 256, attention-free; input already activated by its producer) -------------------
 // Implicit GEMM on v_mfma_f32_16x16x4_f32: D[cout][pos] += W[tap][cout][cin] * X[pos + tap][cin].  F = 128: workgroup = 4 waves =
 // 192 consecutive rows x all 128 couts (wave: 3 position x 8 cout tiles, 96 accumulator registers), <= 162 VGPRs and 34 KB of LDS,
@@ -517,8 +514,8 @@ __device__ __forceinline__ void conv_epilogue_h(f32x4 (&acc)[CT][NPT], const int
 // accumulator tiles, 12 ds_read_b128 per 32 MFMAs).  Stage = (32-channel slice, tap); stages are handled in PAIRS per barrier:
 // 4-slot weight ring (8 KB per slot, global_load_lds one pair ahead), two 32-channel slab buffers (rows + halo, buffer_load..lds,
 // bounds check = zero fill) -- 70 KB of LDS and <= 256 VGPRs, so TWO workgroups share a CU and one computes while the other sits
-// in its barrier, its slab wait or its epilogue.  The kernel is persistent (512 workgroups walk the (row tile, cout half) list):
-// the next tile's first DMAs are issued before the current tile's stores.  Weight traffic: 1.18 MB per 256 rows (~4 TB/s of L2
+// in its barrier, its slab wait or its epilogue.  The kernel can walk a (row tile, cout half) list with the next tile's first
+// DMAs issued before the current tile's stores (gridDim.x a multiple of 16), but is launched with one block per tile.  Weight traffic: 1.18 MB per 256 rows (~4 TB/s of L2
 // reads chip-wide at 1 PFLOP/s).  Measured shares of a 0.88-ms launch (8192 boards, F=256; ablation builds): MFMA loop alone
 // 0.44, DMA issue + traffic 0.17, epilogue 0.22, B-fragment addressing + reads 0.09, barriers 0.03, A reads 0.03.
 // An 8-wave 256x256 tile with one workgroup per CU (64-channel stages) measured 827 vs 888 TFLOP/s for this shape.
@@ -997,7 +994,9 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
             const int grid_h = (M + 255) / 256;                                      // 256-row tiles
             constexpr int COS = F / 128;
             const int nblk_h2 = COS == 1 ? grid_h : (grid_h + 7) / 8 * 8 * COS;      // (row tile, cout part) blocks
-            const int grid_h2 = nblk_h2 < TG_H2_GRID ? nblk_h2 : TG_H2_GRID;       // persistent: 2 workgroups per CU x 256 CUs
+            // one workgroup per block: the kernel can walk a tile list (grid < nblk), but the hardware dispatcher balances
+            // better than a static list -- 512 persistent workgroups measured 0.6-2 % slower
+            const int grid_h2 = nblk_h2;
             const size_t nb = n->blocks.size();
             // stem on the fp16 matrix cores too (input planes are 0/1, exact in fp16; 16 planes padded to 64 channels = 18 stages):
             // writes the f32 residual stream x and the first conv input relu(bn_next(x)) as fp16

@@ -284,6 +284,9 @@ __global__ __launch_bounds__(256, (NPT > 2 ? 2 : 1)) void k_conv3x3(const float*
 // LDS pointer type of the LDS-DMA builtins; counted wait on the in-order vector-memory counter (loads, stores and LDS-DMA share it)
 typedef __attribute__((address_space(3))) void tg_lds_void;
 #define TG_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+// raw s_barrier fenced for the COMPILER on both sides: the LDS-DMA writes are invisible to it (inline assembly, see below), so
+// nothing else stops it from scheduling a fragment read of the next stage above the barrier that publishes that stage
+#define TG_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
 // LDS-DMA pieces (64 lanes x 16 B -> 1 KB of LDS at `lds`, lane-linear) issued as INLINE ASSEMBLY on purpose.  Through the
 // builtins hipcc knows that LDS is being written asynchronously, cannot see that the kernels' own counted s_waitcnt + s_barrier
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sg(const fl
     load_b(b_cur, 0);
     TG_VMCNT(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    TG_BARRIER();
 
 #pragma unroll 1
     for (int pp = 0; pp < NGRP; ++pp) {
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sg(const fl
 #pragma unroll
             for (int t = 0; t < NPT; ++t) b_cur[t] = b_next[t];
         }
-        __builtin_amdgcn_s_barrier();                                    // group pp+1 has landed for everybody; the slots of group pp are free
+        TG_BARRIER();                                    // group pp+1 has landed for everybody; the slots of group pp are free
         if (NGS * (pp + 2) < NST) {
 #pragma unroll
             for (int h = 0; h < NGS; ++h) dma_w(NGS * (pp + 2) + h);
@@ -640,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
         else TG_VMCNT(0);
         first = false;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        TG_BARRIER();
 #ifdef TG_SD_STAMP
         TG_STAMP(t_pro);
 #endif
@@ -684,7 +687,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
 #ifdef TG_SD_STAMP
             TG_STAMP(t_b);
 #endif
-            __builtin_amdgcn_s_barrier();
+            TG_BARRIER();
 #ifdef TG_SD_STAMP
             TG_STAMP(t_c);
             s_cmp += t_a - t_0; s_dma += t_b - t_a; s_bar += t_c - t_b;
@@ -830,7 +833,7 @@ __global__ __launch_bounds__(256, 2) void k_head_h(const _Float16* __restrict__ 
     for (int sl = 0; sl < NSL; ++sl) {
         // slice sl must have landed; the only younger DMAs of this wave are its pieces of slice sl+1
         if (sl + 1 < NSL) vmcnt_uniform<NXQ + 3>(cnt_mine); else TG_VMCNT(0);
-        __builtin_amdgcn_s_barrier();
+        TG_BARRIER();
         f32x4 a[9];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) a[tap] = *reinterpret_cast<const f32x4*>(wsl[sl & 1] + tap * 512 + aoff);
@@ -846,7 +849,7 @@ __global__ __launch_bounds__(256, 2) void k_head_h(const _Float16* __restrict__ 
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a[tap]), __builtin_bit_cast(h8, b), acc[t], 0, 0, 0);
             }
         }
-        __builtin_amdgcn_s_barrier();                                     // every wave is done with buffers sl & 1
+        TG_BARRIER();                                     // every wave is done with buffers sl & 1
         if (sl + 2 < NSL) dma(sl + 2);
     }
     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + kq * 4);

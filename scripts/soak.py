@@ -11,10 +11,12 @@ G = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 SIMS = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 DTYPE = sys.argv[4] if len(sys.argv) > 4 else "f32"
-F, NB = (128, 2) if DTYPE == "f16" else (32, 2)
-cfg = Config(num_simulation=SIMS, num_features=F, num_blocks=NB, inference_dtype=DTYPE)
+S = int(sys.argv[5]) if len(sys.argv) > 5 else 9
+MAXSTEP = int(sys.argv[6]) if len(sys.argv) > 6 else 120
+F, NB = (128, 2) if (DTYPE == "f16" or S == 19) else (32, 2)      # 19x19 is built for 128 and 256 filters
+cfg = Config(num_simulation=SIMS, num_features=F, num_blocks=NB, inference_dtype=DTYPE, board_size=S, max_step=MAXSTEP)
 sp = BatchedSelfPlay(cfg, G)
-sp.set_weights(model.random_weights(9, 10, F, NB, seed=1))
+sp.set_weights(model.random_weights(S, 10, F, NB, seed=1))
 sp.start()
 t0 = time.time(); fin = 0; lens = []; winners = np.zeros(3, np.int64)
 for i in range(STEPS):
@@ -30,5 +32,5 @@ for i in range(STEPS):
               f"arena high-water {st['max_slots']}, {st['sims'] / (time.time() - t0):.0f} sims/s", flush=True)
 st = sp.engine.stats()
 assert st["errors"] == 0, st
-assert fin >= G * (STEPS // 125), (fin, "fewer finished games than the ply limit guarantees")
-print("soak ok:", fin, "games; black/white wins", winners[1], winners[2], "; mean length", round(float(np.mean(lens)), 1))
+assert fin >= G * (STEPS // (MAXSTEP + 5)), (fin, "fewer finished games than the ply limit guarantees")
+print("soak ok:", fin, "games; black/white wins", winners[1], winners[2], "; mean length", round(float(np.mean(lens)), 1) if lens else 0)

@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from transgo_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -68,3 +70,23 @@ def test_get_sub_encode_crops_like_the_reference():
     lib.getSubEncode(enc.ctypes.data_as(ctypes.c_void_p), sub.ctypes.data_as(ctypes.c_void_p), 7, 10, 5)
     assert (sub[0] == enc[:, :7, :7]).all() and (sub[1] == enc[:, :7, 2:]).all() and (sub[2] == enc[:, 2:, :7]).all()
     assert (sub[3] == enc[:, 2:, 2:]).all() and (sub[4] == enc[:, 1:8, 1:8]).all()
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """No CPU fallback: with the shared library absent the package raises at first use instead of computing anything."""
+    import subprocess, sys
+    code = ("import os, sys; os.environ['TG_LIB'] = sys.argv[1]; from transgo_amd import _lib\n"
+            "try:\n    _lib.load()\nexcept _lib.TransgoError as e:\n    print('RAISED', 'not found' in str(e))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code, str(tmp_path / "nope.so")], capture_output=True, text=True, cwd=root, timeout=120)
+    assert "RAISED True" in out.stdout, out.stdout + out.stderr
+
+
+def test_creating_a_context_without_a_gpu_fails_loudly():
+    """On a machine without a GPU tg_create returns an error that the Python wrapper raises (skipped where a GPU exists)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from transgo_amd import _lib
+    with pytest.raises(_lib.TransgoError):
+        _lib.Context(_lib.default_config())

@@ -406,6 +406,10 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sg(const fl
             if (EPI == 1 && m < M) acc[ct][t] = *reinterpret_cast<const f32x4*>(res + (size_t)m * F + ct * 16 + kq * 4);
         }
     }
+#ifdef TG_SD_STAMP
+    unsigned long long t_start, t_pro, t_0, t_a, t_b, t_c, t_loop, t_end, s_vm = 0, s_bar = 0, s_cmp = 0;
+    TG_STAMP(t_start);
+#endif
 #pragma unroll
     for (int g = 0; g < D; ++g) dma_w(g);
     f32x4 b_cur[NPT], b_next[NPT];
@@ -413,6 +417,9 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sg(const fl
     TG_VMCNT(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     TG_BARRIER();
+#ifdef TG_SD_STAMP
+    TG_STAMP(t_pro);
+#endif
 
 #pragma unroll 1
     for (int pp = 0; pp < NGRP; ++pp) {
@@ -420,6 +427,9 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sg(const fl
         for (int h = 0; h < NGS; ++h) {
             const int g = NGS * pp + h;
             const float* wcur = ws[g % D];
+#ifdef TG_SD_STAMP
+            TG_STAMP(t_0);
+#endif
             if (g + 1 < NST) load_b(b_next, g + 1);
             __builtin_amdgcn_sched_barrier(0);                           // keep the loads HERE: hipcc sinks them to their use, a stage later
             f32x4 a_cur = *reinterpret_cast<const f32x4*>(wcur + aoff);
@@ -434,11 +444,23 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sg(const fl
                         acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s4], b_cur[t][s4], acc[ct][t], 0, 0, 0);
                 a_cur = a_next;
             }
+#ifdef TG_SD_STAMP
+            TG_STAMP(t_a);
+#endif
             TG_VMCNT(0);                                                 // B fragments of stage g+1 (and any weight pieces): a stage old
+#ifdef TG_SD_STAMP
+            TG_STAMP(t_b); s_cmp += t_a - t_0; s_vm += t_b - t_a;
+#endif
 #pragma unroll
             for (int t = 0; t < NPT; ++t) b_cur[t] = b_next[t];
         }
+#ifdef TG_SD_STAMP
+        TG_STAMP(t_b);
+#endif
         TG_BARRIER();                                    // group pp+1 has landed for everybody; the slots of group pp are free
+#ifdef TG_SD_STAMP
+        TG_STAMP(t_c); s_bar += t_c - t_b;
+#endif
         if (NGS * (pp + 2) < NST) {
 #pragma unroll
             for (int h = 0; h < NGS; ++h) dma_w(NGS * (pp + 2) + h);
@@ -447,7 +469,18 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sg(const fl
     int mrow[NPT];
 #pragma unroll
     for (int t = 0; t < NPT; ++t) mrow[t] = m0 + (wave * NPT + t) * 16 + j;
+#ifdef TG_SD_STAMP
+    TG_STAMP(t_loop);
+#endif
     conv_epilogue<F, CT, NPT, (EPI == 1 ? 2 : EPI), EPI == 0, true>(acc, mrow, M, 0, kq, out, res, out2, par);
+#ifdef TG_SD_STAMP
+    TG_STAMP(t_end);
+    if (lane == 0) {
+        atomicAdd(&tg_sd_dbg[0], t_pro - t_start); atomicAdd(&tg_sd_dbg[1], s_vm); atomicAdd(&tg_sd_dbg[2], s_bar);
+        atomicAdd(&tg_sd_dbg[3], t_loop - t_pro); atomicAdd(&tg_sd_dbg[4], t_end - t_loop); atomicAdd(&tg_sd_dbg[5], 1ull);
+        atomicAdd(&tg_sd_dbg[7], s_cmp);
+    }
+#endif
 }
 
 // fp16 activation tensors are SLICE-MAJOR: [channels/32][M rows][32 halfs], so the 16 rows x 64 B of a slab DMA piece are one

@@ -39,6 +39,7 @@ struct Net {
     bool pol_att = false; AttW patt; ConvW head_a; std::string arch;
     float* bufQ = nullptr; float* hca = nullptr;   // q|k|v projections [rows][P][1.5F]; policy head conv output
     float* bufAct = nullptr;                       // pre-activated input of the next conv (DMA path)
+    int* tile_ctr = nullptr;                       // [2*NB] tile counters of the persistent conv launches (zeroed per forward)
     int prec = 0;                                  // cfg.net_precision: 0 = f32, 1 = fp16 storage + f32 accumulate (k_conv3x3_h)
     _Float16* stem_h = nullptr; _Float16* head_h = nullptr; _Float16* x0h = nullptr;   // fp16 path: stem [2*9][F][32] (16 planes padded to 64), head [F/32*9][16][32], input [rows][P][64]
     _Float16* wh = nullptr; _Float16* act16 = nullptr; _Float16* h16 = nullptr;   // fp16 path: weights [2*NB][F/32*9][F][32], activations [rows][P][F]
@@ -348,7 +349,8 @@ template <int S, int F, int EPI>
 __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sg(const float* __restrict__ in, float* __restrict__ out,
                                                                        const float* __restrict__ res, const float* __restrict__ Ws,
                                                                        const float* __restrict__ bias, float* __restrict__ out2,
-                                                                       const float* __restrict__ s2, const float* __restrict__ t2, int M) {
+                                                                       const float* __restrict__ s2, const float* __restrict__ t2, int M,
+                                                                       int* __restrict__ ctr) {
     constexpr int P = S * S, CT = F / 16, CC = 16;
     constexpr int NPT = F == 128 ? 3 : 2, TM = 64 * NPT;
     constexpr int WPW = CT / 4;
@@ -356,10 +358,11 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sg(const fl
     static_assert((F == 128 || F == 256) && NST % NGS == 0, "tile geometry");
     __shared__ __attribute__((aligned(16))) float ws[D][F * CC];
     __shared__ __attribute__((aligned(16))) float par[3 * F];
+    __shared__ int next_tile;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, kq = lane >> 4;
-    const int m0 = blockIdx.x * TM;
+    int m0 = blockIdx.x * TM;
     for (int i = tid; i < F; i += 256) { par[i] = bias[i]; par[F + i] = out2 ? s2[i] : 0.f; par[2 * F + i] = out2 ? t2[i] : 0.f; }
 
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, M * F * 4, 0x00020000);
@@ -371,21 +374,16 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sg(const fl
             tg_dma_global(Ws + (size_t)g * (F * CC) + pc * 16 * CC, (prow * CC + pchunk * 4) * 4, (tg_lds_void*)(&ws[g % D][pc * 256]));
         }
     };
+    // F = 256 runs persistent with a DYNAMIC tile list: the first gridDim.x tiles are the block indices, every further tile index
+    // comes from an atomic counter (fetched by one lane while the current tile computes, published through LDS behind the loop's
+    // barriers), so the dispatcher-like balance is kept while the next tile's first weights go out before the current tile's stores
+    // and its residual / first B fragments right after them (+1.2-1.7 %).  At F = 128 (shorter tiles, three workgroups per CU) the
+    // same loop costs 2 %, so there every workgroup takes exactly one tile.
+    constexpr bool PERSIST = F == 256;
+    const int ntiles = (M + TM - 1) / TM;
+    const int aoff = j * CC + ((kq ^ swz64(j)) << 2);
     unsigned vmask[NPT]; int boff[NPT];
-#pragma unroll
-    for (int t = 0; t < NPT; ++t) {
-        const int m = m0 + (wave * NPT + t) * 16 + j;
-        unsigned mk = 0;
-        if (m < M) {
-            const int p = m % P, x = p % S, y = p / S;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-                if (yy >= 0 && yy < S && xx >= 0 && xx < S) mk |= 1u << tap;
-            }
-        }
-        vmask[t] = mk; boff[t] = (m * CC + kq * 4) * 4;                  // byte offset of this lane's 16 B inside slice 0
-    }
+    f32x4 acc[CT][NPT], b_cur[NPT], b_next[NPT];
     auto load_b = [&](f32x4* b, int g) {
         const int sl = g / 9, tap = g % 9;
         const int soff = (sl * M + (tap / 3 - 1) * S + (tap % 3 - 1)) * (CC * 4);       // wave-uniform: slice base + tap shift
@@ -395,92 +393,82 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sg(const fl
             b[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, voff, 0, 0));
         }
     };
-    const int aoff = j * CC + ((kq ^ swz64(j)) << 2);
-    f32x4 acc[CT][NPT];
+    auto tile_setup = [&]() {                                            // masks, accumulator start values and stage-0 fragments of tile m0
 #pragma unroll
-    for (int t = 0; t < NPT; ++t) {
-        const int m = m0 + (wave * NPT + t) * 16 + j;
+        for (int t = 0; t < NPT; ++t) {
+            const int m = m0 + (wave * NPT + t) * 16 + j;
+            unsigned mk = 0;
+            if (m < M) {
+                const int p = m % P, x = p % S, y = p / S;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (EPI == 1 && m < M) acc[ct][t] = *reinterpret_cast<const f32x4*>(res + (size_t)m * F + ct * 16 + kq * 4);
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                    if (yy >= 0 && yy < S && xx >= 0 && xx < S) mk |= 1u << tap;
+                }
+            }
+            vmask[t] = mk; boff[t] = (m * CC + kq * 4) * 4;              // byte offset of this lane's 16 B inside slice 0
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {                            // EPI 1: start from the residual (no loads behind the epilogue's stores)
+                acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (EPI == 1 && m < M) acc[ct][t] = *reinterpret_cast<const f32x4*>(res + (size_t)m * F + ct * 16 + kq * 4);
+            }
         }
-    }
-#ifdef TG_SD_STAMP
-    unsigned long long t_start, t_pro, t_0, t_a, t_b, t_c, t_loop, t_end, s_vm = 0, s_bar = 0, s_cmp = 0;
-    TG_STAMP(t_start);
-#endif
+        load_b(b_cur, 0);
+    };
 #pragma unroll
     for (int g = 0; g < D; ++g) dma_w(g);
-    f32x4 b_cur[NPT], b_next[NPT];
-    load_b(b_cur, 0);
-    TG_VMCNT(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    TG_BARRIER();
-#ifdef TG_SD_STAMP
-    TG_STAMP(t_pro);
-#endif
+    tile_setup();
+    for (;;) {
+        if (PERSIST && tid == 0) next_tile = (int)gridDim.x + atomicAdd(ctr, 1);    // read by everybody after the loop's barriers
+        TG_VMCNT(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        TG_BARRIER();
 
 #pragma unroll 1
-    for (int pp = 0; pp < NGRP; ++pp) {
+        for (int pp = 0; pp < NGRP; ++pp) {
 #pragma unroll
-        for (int h = 0; h < NGS; ++h) {
-            const int g = NGS * pp + h;
-            const float* wcur = ws[g % D];
-#ifdef TG_SD_STAMP
-            TG_STAMP(t_0);
-#endif
-            if (g + 1 < NST) load_b(b_next, g + 1);
-            __builtin_amdgcn_sched_barrier(0);                           // keep the loads HERE: hipcc sinks them to their use, a stage later
-            f32x4 a_cur = *reinterpret_cast<const f32x4*>(wcur + aoff);
+            for (int h = 0; h < NGS; ++h) {
+                const int g = NGS * pp + h;
+                const float* wcur = ws[g % D];
+                if (g + 1 < NST) load_b(b_next, g + 1);
+                __builtin_amdgcn_sched_barrier(0);                       // keep the loads HERE: hipcc sinks them to their use, a stage later
+                f32x4 a_cur = *reinterpret_cast<const f32x4*>(wcur + aoff);
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                f32x4 a_next = a_cur;
-                if (ct + 1 < CT) a_next = *reinterpret_cast<const f32x4*>(wcur + (ct + 1) * 256 + aoff);
+                for (int ct = 0; ct < CT; ++ct) {
+                    f32x4 a_next = a_cur;
+                    if (ct + 1 < CT) a_next = *reinterpret_cast<const f32x4*>(wcur + (ct + 1) * 256 + aoff);
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
+                    for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-                    for (int t = 0; t < NPT; ++t)
-                        acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s4], b_cur[t][s4], acc[ct][t], 0, 0, 0);
-                a_cur = a_next;
+                        for (int t = 0; t < NPT; ++t)
+                            acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s4], b_cur[t][s4], acc[ct][t], 0, 0, 0);
+                    a_cur = a_next;
+                }
+                TG_VMCNT(0);                                             // B fragments of stage g+1 (and any weight pieces): a stage old
+#pragma unroll
+                for (int t = 0; t < NPT; ++t) b_cur[t] = b_next[t];
             }
-#ifdef TG_SD_STAMP
-            TG_STAMP(t_a);
-#endif
-            TG_VMCNT(0);                                                 // B fragments of stage g+1 (and any weight pieces): a stage old
-#ifdef TG_SD_STAMP
-            TG_STAMP(t_b); s_cmp += t_a - t_0; s_vm += t_b - t_a;
-#endif
+            TG_BARRIER();                                                // group pp+1 has landed for everybody; the slots of group pp are free
+            if (NGS * (pp + 2) < NST) {
 #pragma unroll
-            for (int t = 0; t < NPT; ++t) b_cur[t] = b_next[t];
+                for (int h = 0; h < NGS; ++h) dma_w(NGS * (pp + 2) + h);
+            }
         }
-#ifdef TG_SD_STAMP
-        TG_STAMP(t_b);
-#endif
-        TG_BARRIER();                                    // group pp+1 has landed for everybody; the slots of group pp are free
-#ifdef TG_SD_STAMP
-        TG_STAMP(t_c); s_bar += t_c - t_b;
-#endif
-        if (NGS * (pp + 2) < NST) {
+        int mrow[NPT];
 #pragma unroll
-            for (int h = 0; h < NGS; ++h) dma_w(NGS * (pp + 2) + h);
+        for (int t = 0; t < NPT; ++t) mrow[t] = m0 + (wave * NPT + t) * 16 + j;
+        const int next = PERSIST ? __builtin_amdgcn_readfirstlane(next_tile) : ntiles;     // written before the loop's first barrier
+        const bool more = next < ntiles;
+        if (more) {                                                      // every wave is past the last barrier: the ring is free
+#pragma unroll
+            for (int g = 0; g < D; ++g) dma_w(g);
         }
+        conv_epilogue<F, CT, NPT, (EPI == 1 ? 2 : EPI), EPI == 0, true>(acc, mrow, M, 0, kq, out, res, out2, par);
+        if (!more) break;
+        m0 = next * TM;
+        tile_setup();
+        TG_BARRIER();                                                    // everybody has read next_tile before it is overwritten
     }
-    int mrow[NPT];
-#pragma unroll
-    for (int t = 0; t < NPT; ++t) mrow[t] = m0 + (wave * NPT + t) * 16 + j;
-#ifdef TG_SD_STAMP
-    TG_STAMP(t_loop);
-#endif
-    conv_epilogue<F, CT, NPT, (EPI == 1 ? 2 : EPI), EPI == 0, true>(acc, mrow, M, 0, kq, out, res, out2, par);
-#ifdef TG_SD_STAMP
-    TG_STAMP(t_end);
-    if (lane == 0) {
-        atomicAdd(&tg_sd_dbg[0], t_pro - t_start); atomicAdd(&tg_sd_dbg[1], s_vm); atomicAdd(&tg_sd_dbg[2], s_bar);
-        atomicAdd(&tg_sd_dbg[3], t_loop - t_pro); atomicAdd(&tg_sd_dbg[4], t_end - t_loop); atomicAdd(&tg_sd_dbg[5], 1ull);
-        atomicAdd(&tg_sd_dbg[7], s_cmp);
-    }
-#endif
 }
 
 // fp16 activation tensors are SLICE-MAJOR: [channels/32][M rows][32 halfs], so the 16 rows x 64 B of a slab DMA piece are one
@@ -1066,6 +1054,7 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
             // prologue-free chain: every producer also writes relu(bn_next(.)) for its consumer
             const size_t nb = n->blocks.size();
             const float* s0 = nb ? n->blocks[0].s1 : n->s_end; const float* t0 = nb ? n->blocks[0].t1 : n->t_end;
+            if (nb) (void)hipMemsetAsync(n->tile_ctr, 0, sizeof(int) * 2 * nb, st);     // dynamic tile counters of the conv launches
             hipLaunchKernelGGL((k_conv3x3<S, 16, F, false, 0, 9, 2, true>), dim3(grid), dim3(256), 0, st, (const float*)n->x0, x,
                                (const float*)nullptr, n->stem.w, n->stem.b, (const float*)nullptr, (const float*)nullptr, M,
                                nb ? n->bufAct : (float*)nullptr, s0, t0);
@@ -1074,14 +1063,16 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                 const float* sn = i + 1 < nb ? n->blocks[i + 1].s1 : n->s_end;
                 const float* tn = i + 1 < nb ? n->blocks[i + 1].t1 : n->t_end;
                 constexpr int SD_TM = F == 128 ? 192 : 128;
-                const int grid_sd = (M + SD_TM - 1) / SD_TM;
+                const int ntile_sd = (M + SD_TM - 1) / SD_TM, slots_sd = F == 128 ? ntile_sd : 512;  // F=256: 2 resident workgroups x 256 CUs walk a dynamic tile list
+                const int grid_sd = ntile_sd < slots_sd ? ntile_sd : slots_sd;
+                int* const ctr1 = n->tile_ctr + 2 * i; int* const ctr2 = ctr1 + 1;                  // zeroed at the top of the forward
                 float* const actn = i + 1 < nb ? n->bufAct : (float*)nullptr;
                 { ProfScope ps(n, st, conv_flops);
                   hipLaunchKernelGGL((k_conv3x3_sg<S, F, 0>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufAct, n->bufH,
-                                     (const float*)nullptr, b.g1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M); }
+                                     (const float*)nullptr, b.g1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, ctr1); }
                 { ProfScope ps(n, st, conv_flops);
                   hipLaunchKernelGGL((k_conv3x3_sg<S, F, 1>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufH, y,
-                                     (const float*)x, b.g2, b.c2.b, actn, sn, tn, M); }
+                                     (const float*)x, b.g2, b.c2.b, actn, sn, tn, M, ctr2); }
                 float* t = x; x = y; y = t;
             }
             // bufAct / bufH are slice-major; the head conv reads the row-major residual stream and activates it while staging
@@ -1244,6 +1235,7 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
         const size_t wcopy = (size_t)(NB > 0 ? 2 * NB : 1) * 9 * F * F;
         if (n->dma) TG_HIP(ctx, hipMalloc((void**)&n->wstage, sizeof(float) * wcopy));
         if (n->dma) TG_HIP(ctx, hipMalloc((void**)&n->bufAct, act));
+        if (n->dma) TG_HIP(ctx, hipMalloc((void**)&n->tile_ctr, sizeof(int) * (size_t)(NB > 0 ? 2 * NB : 1)));
         if (prec == 1) {
             TG_HIP(ctx, hipMalloc((void**)&n->wh, sizeof(_Float16) * wcopy));
             TG_HIP(ctx, hipMalloc((void**)&n->act16, act / 2));
@@ -1320,7 +1312,7 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
 void tg_net_destroy(tg_ctx* ctx) {
     if (!ctx || !ctx->eng || !ctx->eng->net) return;
     Net* n = ctx->eng->net;
-    void* ptrs[] = {n->blob, n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->bufQ, n->hca, n->bufAct, n->wstage, n->wh, n->act16, n->h16, n->stem_h, n->head_h, n->x0h};
+    void* ptrs[] = {n->blob, n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->bufQ, n->hca, n->bufAct, n->wstage, n->wh, n->act16, n->h16, n->stem_h, n->head_h, n->x0h, n->tile_ctr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t ev : n->ev) (void)hipEventDestroy(ev);
     delete n;

@@ -89,26 +89,27 @@ def test_reference_replayed_network(golden_dir):
     _replay_fixture(blob, "real_s11_n64", lookup)
 
 
-def test_many_games_vs_oracle():
-    """32 concurrent games with different seeds against 32 sequential oracle runs."""
+@pytest.mark.parametrize("S,G,sims,moves,max_step", [(9, 32, 48, 24, 120), (19, 6, 40, 10, 450)])
+def test_many_games_vs_oracle(S, G, sims, moves, max_step):
+    """Concurrent games with different seeds against sequential oracle runs, at both board sizes."""
     from oracle.go_oracle import OracleGoEnv
     from oracle.wp_mcts import OracleSearch
-    G, sims, moves = 32, 48, 24
+    A = S * S + 1
     fn = evaluators.sharp
     seeds = np.arange(100, 100 + G)
-    eng = _engine(fn, G, sims)
+    eng = _engine(fn, G, sims, board_size=S, max_step=max_step)
     eng.reset(seeds)
     orcs = []
     for s in seeds:
         rng = np.random.RandomState(int(s))
-        orcs.append((OracleSearch(OracleGoEnv(), fn, rng, num_simulation=sims), rng))
+        orcs.append((OracleSearch(OracleGoEnv(board_size=S, max_step=max_step), fn, rng, num_simulation=sims, board_size=S), rng))
     for m in range(moves):
         eng.search()
         vis, rn, pl, st, ob = eng.root_info()
         acts, pis = eng.choose_moves(vis, st)
         for g, (o, rng) in enumerate(orcs):
             a, pi, obs, info = o.search_move()
-            raw = np.array([o.root.kids[i].n if i in o.root.kids else 0 for i in range(82)])
+            raw = np.array([o.root.kids[i].n if i in o.root.kids else 0 for i in range(A)])
             assert (vis[g] == raw).all(), (g, m)
             assert a == acts[g] and (pi == pis[g]).all() and (obs == ob[g]).all(), (g, m)
             o.advance(a)

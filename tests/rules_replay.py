@@ -60,3 +60,27 @@ def replay(env, blob, games=None):
             checked += 1
         i = j
     return checked
+
+
+def replay_encode_variants(make_env, blob):
+    """tests/golden/rules_enc_variants_s9.npz: the 9- and 13-plane encodings (go_env.cc:96-115) recorded from the compiled
+    reference engine at every 4th position of seeded random games.  `make_env(encode_dim)` builds an env with that encoding."""
+    envs = {9: make_env(9), 13: make_env(13)}
+    checked = 0
+    for g in range(len(blob["action"])):
+        rows = np.flatnonzero(blob["game"] == g)
+        plies = {int(blob["ply"][r]): r for r in rows}
+        states = {d: e.reset()[0] for d, e in envs.items()}
+        for ply, act in enumerate(blob["action"][g]):
+            if act < 0:
+                break
+            if ply in plies:
+                r = plies[ply]
+                for d, key in ((9, "obs9"), (13, "obs13")):
+                    obs = envs[d].encode(states[d])
+                    assert obs.shape == (d, 9, 9) and obs.dtype == np.float32
+                    assert (obs.reshape(-1).astype(np.uint8) == unpack(blob[key][r], d * 81)).all(), (d, g, ply)
+                    checked += 1
+            for d, e in envs.items():
+                states[d], _ = e.step(states[d], int(act))
+    return checked

@@ -140,3 +140,15 @@ def test_rules_fixture_19x19_gpu(golden_dir):
     c = C(); c.board_size = 19; c.max_step = int(blob["max_step"]); c.komi = 7.5; c.encode_state_channels = 10
     n = rules_replay.replay(GoEnv(c), blob)
     assert n > 1500
+
+
+def test_encode_9_and_13_planes_match_the_reference_engine_gpu(golden_dir):
+    """The two feature encodings the reference's Python never selects (encode9 / encode13, board_feature.cc:213-253)."""
+    from transgo_amd.environment import GoEnv
+
+    def make(d):
+        class C: pass
+        c = C(); c.board_size = 9; c.max_step = 120; c.komi = 7.5; c.encode_state_channels = d
+        return GoEnv(c)
+    blob = rules_replay.load(golden_dir, "rules_enc_variants_s9.npz")
+    assert rules_replay.replay_encode_variants(make, blob) > 2000

@@ -85,3 +85,10 @@ def test_rules_fixture_19x19(golden_dir):
     blob = rules_replay.load(golden_dir, "rules_s19.npz")
     n = rules_replay.replay(OracleGoEnv(board_size=19, max_step=int(blob["max_step"])), blob)
     assert n > 1500
+
+
+def test_encode_9_and_13_planes_match_the_reference_engine(golden_dir):
+    from tests import rules_replay
+    blob = rules_replay.load(golden_dir, "rules_enc_variants_s9.npz")
+    n = rules_replay.replay_encode_variants(lambda d: OracleGoEnv(encode_dim=d), blob)
+    assert n > 2000

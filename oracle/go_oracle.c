@@ -240,8 +240,10 @@ int og_step(const og_cfg *cfg, const og_state *st, og_state *next, int action, i
 /* go_env.cc:85-89 */
 int og_check_action(const og_cfg *cfg, const og_state *st, int action) {
     const int P = cfg->size * cfg->size;
-    if (action == P || action == OG_PASS || action == OG_RESIGN) return 1;
-    if (action < 0 || action > P) return 0;
+    /* go_env.cc:84-88 hands the coordinate to TryPlay2 untranslated (only Step maps S*S to PASS): the internal PASS / RESIGN codes
+     * are "playable" (board.cc:440-445), S*S itself is off the board (board.cc:448-451) */
+    if (action == OG_PASS || action == OG_RESIGN) return 1;
+    if (action < 0 || action >= P) return 0;
     og_groups g; analyze(cfg, st, &g);
     return legal_point(cfg, st, &g, action, st->next_player);
 }

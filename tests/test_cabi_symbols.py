@@ -72,6 +72,24 @@ def test_get_sub_encode_crops_like_the_reference():
     assert (sub[3] == enc[:, 2:, 2:]).all() and (sub[4] == enc[:, 1:8, 1:8]).all()
 
 
+def test_get_sub_encode_equals_the_compiled_reference():
+    """Same call into oracle/_ref (the reference engine compiled in place by `make -C oracle ref`; it travels to the GPU box as a
+    built artefact) and into this library, for every cut count and two window sizes."""
+    import numpy as np
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "GoEnv", "go_env.so")
+    if not os.path.exists(ref_so):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    ref, lib = ctypes.CDLL(ref_so), ctypes.CDLL(_lib.LIB_PATH)
+    rs = np.random.RandomState(3)
+    for sub_size in (7, 5):
+        for cuts in (1, 4, 5):
+            enc = (rs.rand(10, 9, 9) < 0.3).astype(np.float32)
+            a = np.full((5, 10, sub_size, sub_size), -1, np.float32); b = a.copy()
+            for L, out in ((ref, a), (lib, b)):
+                L.getSubEncode(enc.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), sub_size, 10, cuts)
+            assert np.array_equal(a, b), (sub_size, cuts)
+
+
 def test_missing_library_fails_loudly(tmp_path):
     """No CPU fallback: with the shared library absent the package raises at first use instead of computing anything."""
     import subprocess, sys

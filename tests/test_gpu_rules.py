@@ -50,6 +50,10 @@ def _lockstep(S, n_games, max_step, seed, pass_p):
             sc, te = oenv.getScoreAndTerritory(o)
             assert q["score"][g] == np.float32(sc) and (q["terr"][g] == te).all(), ("score", S, g, plies)
             assert q["player"][g] == oenv.getPlayer(o) and q["step"][g] == oenv.getStep(o)
+            if g == 0 and plies % 8 == 0:                # single-state wrapper incl. the pass index (off the board for checkAction)
+                st0 = hs[0].tobytes()
+                for c in (P, -1, -2, int(la[0]), P + 3):
+                    assert henv.checkAction(st0, c) == oenv.checkAction(o, c), ("checkAction", c)
             r = rng.rand()
             if r < pass_p:
                 acts[g] = P

@@ -58,6 +58,7 @@ def test_against_compiled_reference_19x19_logic_is_size_generic():
     lib.Init(1, 10, 120, 7.5)
     lib.Step.restype = ctypes.c_bool
     lib.getScore.restype = ctypes.c_float
+    lib.checkAction.restype = ctypes.c_bool; lib.isTerminated.restype = ctypes.c_bool
     env = OracleGoEnv()
     rng = np.random.RandomState(99)
     for g in range(40):
@@ -72,7 +73,12 @@ def test_against_compiled_reference_19x19_logic_is_size_generic():
             e = np.zeros(810, np.float32); lib.Encode(a, e.ctypes.data_as(ctypes.c_void_p))
             assert (e == env.encode(b).reshape(-1)).all()
             assert lib.getScore(a) == env.getScore(b)
-            act = la[rng.randint(len(la))]
+            if env.getStep(b) % 16 == 1:                 # the reference prints a line for every refusal: sample, do not flood
+                for c in (81, -1, -2):                   # S*S is NOT translated to PASS here (only Step does that); -1 / -2 are
+                    assert bool(lib.checkAction(a, ctypes.c_int(c))) == bool(env.checkAction(b, c)), c
+            assert bool(lib.isTerminated(a)) == bool(env.isTerminated(b))
+            assert (lib.getPlayer(a) & 0xFF) == env.getPlayer(b) and lib.getStep(a) == env.getStep(b)
+            act = la[rng.randint(len(la))] if rng.rand() > 0.04 else 81
             a2 = ctypes.create_string_buffer(1200)
             d1 = lib.Step(a, a2, ctypes.c_int(act)); a = a2
             b, d2 = env.step(b, act)

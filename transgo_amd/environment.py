@@ -110,11 +110,11 @@ class GoEnv:
     def isTerminated(self, state):
         return bool(self.query_batch(self._one(state), meta=True)["terminated"][0])
 
-    def checkAction(self, state, action):                     # environment.py:155-156 (TryPlay2: pass/resign legal)
+    def checkAction(self, state, action):                     # environment.py:155-156 -> go_env.cc:84-88 -> TryPlay2 (board.cc:437-464)
         action = int(action)
-        if action in (self.P, -1, -2):
+        if action in (-1, -2):                                # the engine's internal PASS / RESIGN codes are "playable"
             return True
-        if action < 0 or action > self.P:
+        if action < 0 or action >= self.P:                    # S*S is only translated to PASS by step(); here it is off the board
             return False
         return bool(self.query_batch(self._one(state), legal=True)["legal"][0][action])
 

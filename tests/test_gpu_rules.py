@@ -156,3 +156,60 @@ def test_encode_9_and_13_planes_match_the_reference_engine_gpu(golden_dir):
         return GoEnv(c)
     blob = rules_replay.load(golden_dir, "rules_enc_variants_s9.npz")
     assert rules_replay.replay_encode_variants(make, blob) > 2000
+
+
+def test_compat_abi_in_lockstep_with_the_compiled_reference():
+    """Every one of the 15 go_env.h symbols, called with identical arguments on this library and on oracle/_ref (the reference
+    engine compiled in place; a built artefact that travels with the snapshot): return values and output buffers must agree call
+    by call over seeded random games, including refused moves, the in-place Step_, steps on finished games, checkAction on every
+    coordinate from RESIGN to S*S, and getSubEncode."""
+    import ctypes, os
+    from transgo_amd import _lib
+    ref_so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "GoEnv", "go_env.so")
+    if not os.path.exists(ref_so):
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    libs = [ctypes.CDLL(ref_so), ctypes.CDLL(_lib.LIB_PATH)]
+    for L in libs:
+        L.Init.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float]
+        for f in ("Step", "Step_", "checkAction", "isTerminated", "Reset", "Encode"):
+            getattr(L, f).restype = ctypes.c_bool
+        L.getScore.restype = ctypes.c_float; L.getTerritory.restype = ctypes.c_float
+        L.Init(1, 10, 60, 7.5)
+    P = 81
+    rng = np.random.RandomState(515)
+    new = lambda: ctypes.create_string_buffer(2048)
+    calls = 0
+    for g in range(12):
+        st = [new(), new()]
+        assert libs[0].Reset(st[0]) == libs[1].Reset(st[1])
+        done = False; extra = 2
+        while extra:
+            outs = []
+            for L, s in zip(libs, st):
+                la = (ctypes.c_int * (P + 1))(); n1 = L.getLegalAction(s, la)
+                ne = (ctypes.c_int * (P + 1))(); n2 = L.getLegalNoEye(s, ne)
+                enc = np.zeros(10 * P, np.float32); L.Encode(s, enc.ctypes.data_as(ctypes.c_void_p))
+                ter = np.zeros(P, np.float32); sc2 = L.getTerritory(s, ter.ctypes.data_as(ctypes.c_void_p))
+                sub = np.zeros(5 * 10 * 49, np.float32)
+                L.getSubEncode(enc.ctypes.data_as(ctypes.c_void_p), sub.ctypes.data_as(ctypes.c_void_p), 7, 10, 5)
+                chk = [bool(L.checkAction(s, ctypes.c_int(c))) for c in (-2, -1, P, 0, 13, 40, 67, 80)]
+                outs.append((list(la[:n1]), list(ne[:n2]), enc, float(L.getScore(s)), float(sc2), ter, sub, chk,
+                             L.getPlayer(s) & 0xFF, L.getStep(s), bool(L.isTerminated(s))))
+            a, b = outs
+            for i, (x, y) in enumerate(zip(a, b)):
+                assert np.array_equal(np.asarray(x), np.asarray(y)), (g, "field", i)
+            calls += 1
+            legal = [c for c in a[0] if c != P] or [P]
+            r = rng.rand()
+            act = P if r < 0.05 else int(rng.randint(P)) if r < 0.10 else int(legal[rng.randint(len(legal))])
+            if rng.rand() < 0.5:
+                nx = [new(), new()]
+                d = [bool(L.Step(s, n, ctypes.c_int(act))) for L, s, n in zip(libs, st, nx)]
+                st = nx
+            else:
+                d = [bool(L.Step_(s, ctypes.c_int(act))) for L, s in zip(libs, st)]
+            assert d[0] == d[1], (g, "done")
+            if done:
+                extra -= 1                                   # two more calls on a finished game
+            done = done or d[0]
+    assert calls > 300

@@ -210,3 +210,18 @@ def test_bench_rooflines_are_computed_from_measured_inputs():
     assert bench.tree_roofline(9, 10, 0, 0, 0, 0, 0.0, 0) is None
     assert "k_conv3x3_sg<9,128>" in bench.kernel_name(9, 128, "f32") and "k_conv3x3_h2<19,256>" in bench.kernel_name(19, 256, "f16")
     assert bench.kernel_name(9, 64, "f32").startswith("k_conv3x3<9,64,64>")
+
+
+def test_storage_classes_reproduce_the_reference_scenario(golden_dir):
+    """tests/golden/storage.npz was recorded by running tests/golden/gen_storage.py::scenario on the reference's own
+    ReplayMemory_Random / SharedStorage; the same function on this package's classes must give the same data."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_storage_scn", os.path.join(golden_dir, "gen_storage.py"))
+    src = open(spec.origin).read().replace("import ref_harness  # noqa: E402", "")     # the scenario itself needs no reference
+    ns = {"__name__": "gen_storage_scn", "__file__": spec.origin}
+    exec(compile(src, spec.origin, "exec"), ns)
+    got = ns["scenario"](ReplayMemory_Random, SharedStorage, Config())
+    want = _load(golden_dir, "storage.npz")
+    assert set(got) == set(want)
+    for k in want:
+        assert np.array_equal(np.asarray(got[k]), want[k]), k

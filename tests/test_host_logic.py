@@ -225,3 +225,18 @@ def test_storage_classes_reproduce_the_reference_scenario(golden_dir):
     assert set(got) == set(want)
     for k in want:
         assert np.array_equal(np.asarray(got[k]), want[k]), k
+
+
+def test_config_defaults_equal_the_reference(golden_dir):
+    """Every scalar default this package's Config shares with the reference's (recorded by tests/golden/gen_config.py), and
+    the temperature schedule of configure.py:75-79 at a few plies."""
+    import json
+    from transgo_amd.engine import temperature
+    ref = json.load(open(os.path.join(golden_dir, "config_defaults.json")))
+    mine = vars(Config())
+    shared = [k for k in ref if k in mine]
+    assert len(shared) >= 20
+    for k in shared:
+        assert mine[k] == ref[k], k
+    for step, t in ref["temperature_at"].items():
+        assert temperature(int(step)) == t

@@ -150,3 +150,17 @@ def test_fp16_self_play_through_the_host_mirror():
     assert len(finished) >= 16 and sp.engine.stats()["errors"] == 0
     obs, pi, z, own = sp.targets(finished[0])[0]
     assert obs.shape == (10, 9, 9) and abs(pi.sum() - 1.0) < 1e-9 and z in (-1.0, 1.0) and own.shape == (81,)
+
+
+def test_plain_c_host_drives_the_engine_through_the_c_abi(tmp_path):
+    """examples/c_host_min.c: no Python and no torch between the caller and libtransgo_hip.so."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_host_min")
+    libdir = os.path.join(root, "transgo_amd")
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_host_min.c"),
+                           "-L" + libdir, "-ltransgo_hip", "-Wl,-rpath," + libdir, "-lm", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "c_host_min ok" in out.stdout, out.stdout + out.stderr
+    sims = int(out.stdout.split("c_host_min ok: ")[1].split()[0])
+    assert sims >= 3 * 8 * 32

@@ -7,9 +7,14 @@
 Workload (BASELINE.json configs[1]): 9x9 Go, 400 simulations/move, 6-block x 128-filter tower (random-init weights),
 4096 concurrent boards per GPU, self-play from empty boards with Dirichlet root noise; game seeds 1000*rank + g.
 A step = one move of every board: root noise, ~100 search waves (tree kernels + network forward on each leaf batch),
-visit counts -> pi and sampled move on the host, re-rooting, and the gather of finished games to rank 0.
-Boards live in HBM throughout; nothing is staged from the host inside the timed region except G actions per step.
-`value` = completed simulations (root visit increments) of all ranks / max-over-ranks wall time.
+visit counts -> pi and sampled move on the host, the move's record entry + re-rooting on the device, and for the games that
+move finished: scoring + target generation on the device (tg_sp_harvest), the gather to rank 0 (RCCL, device buffers) and
+the append into the device-resident replay store (tg_replay_append_dev), then the restart of their slots.
+The boards are staggered before the warm-up (slot g is g mod max_step plies into its game, reached by real self-play with
+8-simulation searches), so the timed steps see the steady state of a running pipeline: ~G/max_step games finish on every
+step.  Boards live in HBM throughout; per step the host receives G*(A+1) int32 visit counts and sends G actions.
+`value` = completed simulations (root visit increments) of all ranks / max-over-ranks wall time; `games_per_hour` =
+games finished (and stored) inside the timed region / the same wall time.
 """
 import argparse
 import ctypes
@@ -33,8 +38,20 @@ def flops_per_leaf(S, C, F, N):
 
 
 # ---- CPU baseline leg (the ONLY part of this file that touches oracle/) -------------------------------------------------------
+def usable_cores():
+    """Host cores this process may actually use: scheduler affinity, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def _cpu_worker(args):
-    seed, budget_s, sims, F, N = args
+    seed, budget_s, sims, F, N, max_step = args
     import torch
     torch.set_num_threads(1)
     from oracle.go_oracle import OracleGoEnv
@@ -50,27 +67,39 @@ def _cpu_worker(args):
             p, v, _ = net.main_prediction(torch.from_numpy(obs))
         return p.numpy(), v.numpy()
     rng = np.random.RandomState(seed)
-    s = OracleSearch(OracleGoEnv(), ev, rng, num_simulation=sims)
-    t0 = time.time()
-    moves = 0
-    while time.time() - t0 < budget_s:
+    s = OracleSearch(OracleGoEnv(max_step=max_step), ev, rng, num_simulation=sims)
+    t_end = time.time() + budget_s
+    moves = games = ply = 0
+    sims_timed, t_timed = 0, 0.0
+    while time.time() < t_end:
+        t0, n0 = time.time(), s.sims_done
         a, _, _, _ = s.search_move()
-        moves += 1
-        if s.advance(a):
-            s.reset_root()
-    return s.sims_done, time.time() - t0, moves
+        done = s.advance(a)
+        if ply >= 10:                                    # the first 10 plies of each game are not timed
+            sims_timed += s.sims_done - n0; t_timed += time.time() - t0
+        moves += 1; ply += 1
+        if done:
+            s.reset_root(); games += 1; ply = 0
+    return sims_timed, t_timed, moves, games
 
 
-def cpu_baseline(budget_s=12.0, sims=400, F=128, N=6):
+def cpu_baseline(budget_s=60.0, sims=400, F=128, N=6, max_step=120, label="C2"):
+    """P = every usable host core, one oracle self-play game per process (leaf batch 4, torch CPU pinned
+    to 1 thread), a fixed window per process, game seeds 1000*rank + g with rank = 0."""
     import multiprocessing as mp
-    procs = max(1, min(os.cpu_count() or 1, 16))
+    procs = usable_cores()
     ctx = mp.get_context("spawn")
     with ctx.Pool(procs) as pool:
-        res = pool.map(_cpu_worker, [(9000 + i, budget_s, sims, F, N) for i in range(procs)])
-    total = sum(r[0] / r[1] for r in res)
-    return {"value": round(total, 1), "unit": "sims/s", "cores": procs, "kind": "port",
+        res = pool.map(_cpu_worker, [(g, budget_s, sims, F, N, max_step) for g in range(procs)])
+    total = sum(r[0] / r[1] for r in res if r[1] > 0)
+    moves = sum(r[2] for r in res)
+    return {"value": round(total, 1), "unit": "sims/s", "cores": procs, "os_cpu_count": os.cpu_count(), "kind": "port",
+            "per_core": round(total / procs, 1), "config": label,
+            "moves_per_hour": round(moves / budget_s * 3600.0, 1),
+            "games_per_hour_equiv": round(moves / budget_s * 3600.0 / max_step, 2),
             "sample": f"{procs} processes x {budget_s:.0f}s of oracle WP_MCTS self-play (oracle/wp_mcts.py + go_oracle.c + torch "
-                      f"CPU 1 thread each), 9x9, {sims} sims/move, {N}x{F} tower, leaf batch 4; {sum(r[2] for r in res)} moves"}
+                      f"CPU 1 thread each), 9x9, {sims} sims/move, {N}x{F} tower, leaf batch 4, first 10 plies of a game untimed; "
+                      f"{moves} moves, {sum(r[3] for r in res)} games finished"}
 
 
 def tree_roofline(S, C, sims, evals, depth_sum, children_scored, tree_ms, waves):
@@ -103,6 +132,19 @@ def kernel_name(S, filters, dtype):
     return f"k_conv3x3<{S},{filters},{filters}> (fp32 MFMA 16x16x4 implicit GEMM)"
 
 
+def stagger(sp, period, sims=8):
+    """Put slot g exactly (g mod period) plies into its game by real self-play with cheap searches: `period - 1` untimed moves
+    of every board, slot g restarted (fresh seed, empty board, empty record) just before the move that leaves it at its
+    offset.  Every record entry the timed steps later harvest was written by the engine's own tg_sp_play."""
+    T0 = period - 1
+    offs = np.arange(sp.G) % period
+    for s_ in range(T0):
+        m = offs == (T0 - s_)
+        if s_ > 0 and m.any():
+            sp._reset(m)
+        sp.advance(num_simulation=sims)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,8 +158,13 @@ def main():
     ap.add_argument("--max-step", type=int, default=0, help="ply limit (default 120 at 9x9, 450 at 19x19)")
     ap.add_argument("--dtype", choices=["f32", "f16"], default="f32",
                     help="network arithmetic: f32 (BASELINE metric, parity 1e-3) or f16 storage + f32 accumulate (configs[4])")
+    ap.add_argument("--network", choices=["tower", "transgo"], default="tower",
+                    help="tower = BASELINE.json's N-block x F-filter net; transgo = the reference's shipped MainNetwork (model.py:41-114)")
+    ap.add_argument("--stagger", type=int, default=-1,
+                    help="spread the boards over this many ply offsets before the warm-up (default: max_step at 9x9, 0 = all "
+                         "boards start together, at 19x19)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=60.0, help="window of each CPU-baseline leg (BASELINE.md 4: 60 s)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,9 +172,11 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.board == 9:
-        cpu = cpu_baseline(a.cpu_seconds, a.sims, a.filters, a.blocks)      # before any GPU context exists
+    cpu = cpu_c1 = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.board == 9 and a.network == "tower":
+        # before any GPU context exists; C2's net for the like-for-like ratio, C1 (plumbing config) beside it
+        cpu = cpu_baseline(a.cpu_seconds, a.sims, a.filters, a.blocks, label="C2 net" if (a.sims, a.filters, a.blocks) == (400, 128, 6) else "bench net")
+        cpu_c1 = cpu_baseline(a.cpu_seconds, 64, 32, 2, label="C1")
 
     import torch
     import torch.distributed as dist
@@ -144,36 +193,57 @@ def main():
 
     from transgo_amd import model
     from transgo_amd.configure import Config
-    from transgo_amd.distributed import gather_records
+    from transgo_amd.distributed import gather_harvest
+    from transgo_amd.replay_buffer import DeviceReplayMemory
     from transgo_amd.self_play import BatchedSelfPlay
 
     S = a.board
     cfg = Config(num_simulation=a.sims, num_features=a.filters, num_blocks=a.blocks, board_size=S,
-                 max_step=a.max_step or (120 if S == 9 else 450), inference_dtype=a.dtype)
-    sp = BatchedSelfPlay(cfg, a.games, device=local if backend == "nccl" else 0, rank=rank, world=world)
-    sp.set_weights(model.random_weights(S, 10, a.filters, a.blocks, seed=1234))
+                 max_step=a.max_step or (120 if S == 9 else 450), inference_dtype=a.dtype, network=a.network)
+    gpu = local if backend == "nccl" else 0
+    sp = BatchedSelfPlay(cfg, a.games, device=gpu, rank=rank, world=world)
+    if a.network == "transgo":
+        sp.set_weights(model.random_transgo_weights(S, 10, a.filters, seed=1234))
+    else:
+        sp.set_weights(model.random_weights(S, 10, a.filters, a.blocks, seed=1234))
+    # rank 0 owns the replay store (north_star: "RCCL gather of (s, pi, z) tuples into the replay buffer"); sized for every
+    # position the run can produce
+    mem = DeviceReplayMemory(cfg, capacity_positions=max(1024, world * a.games * (a.steps + a.warmup + 2)), device=gpu) \
+        if rank == 0 else None
     sp.start()
+    period = a.stagger if a.stagger >= 0 else (cfg.max_step if S == 9 else 0)
+    t_st = time.perf_counter()
+    if period > 1:
+        stagger(sp, period)
+    stagger_s = time.perf_counter() - t_st
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    gathered = 0
+    tally = {"games": 0, "positions": 0}
+
+    def one_step():
+        h = sp.advance(device=True)
+        for hb in gather_harvest(h, S, 10, dst=0, device_index=gpu):      # rank 0: every rank's finished games
+            mem.append_harvest(hb)
+            tally["games"] += hb.n_games; tally["positions"] += hb.n_positions
+
     for _ in range(a.warmup):
-        fin = sp.step()
-        gathered += len(gather_records(fin, S, 10, 0, cdev))
+        one_step()
+    tally["games"] = tally["positions"] = 0
     eng = sp.engine
     eng.ctx.call("tg_prof_enable", 1, 8192)
     eng.ctx.call("tg_prof_enable_tree", 1, 8192)
     cs0 = ctypes.c_uint64()
     eng.ctx.call("tg_prof_read_tree", None, None, None, ctypes.byref(cs0))
     st0 = eng.stats()
+    fin0, drop0 = sp.games_finished, sp.games_dropped
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        fin = sp.step()
-        gathered += len(gather_records(fin, S, 10, 0, cdev))
+        one_step()
     barrier()
     dt = time.perf_counter() - t0
     st1 = eng.stats()
@@ -184,35 +254,45 @@ def main():
 
     sims = st1["sims"] - st0["sims"]; evals = st1["evals"] - st0["evals"]; depth = st1["depth_sum"] - st0["depth_sum"]
     t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-    s = torch.tensor([float(sims), float(evals), float(depth)], dtype=torch.float64, device=cdev)
+    s = torch.tensor([float(sims), float(evals), float(depth), float(sp.games_finished - fin0), float(sp.games_dropped - drop0)],
+                     dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
-    dt = float(t.item()); sims_all, evals_all, depth_all = [float(x) for x in s.tolist()]
+    dt = float(t.item()); sims_all, evals_all, depth_all, fin_all, drop_all = [float(x) for x in s.tolist()]
 
     if rank == 0:
         # HBM bytes per launch of the dominant kernel come from PMC passes (separate rocprofv3 runs, committed under profiles/);
         # they only describe the configuration they were collected on
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json" if a.dtype == "f32" else "r1_pmc_traffic_f16.json")
-        if os.path.exists(tfile) and (S, a.filters, a.games) == (9, 128, 4096):
+        if os.path.exists(tfile) and (S, a.filters, a.games, a.network) == (9, 128, 4096, "tower"):
             with open(tfile) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch_mean")
         value = sims_all / dt
         conv_tflops = (fl.value / (ms.value * 1e-3)) / 1e12 if ms.value > 0 else 0.0
-        fpl = flops_per_leaf(S, 10, a.filters, a.blocks)
+        fpl = flops_per_leaf(S, 10, a.filters, a.blocks) if a.network == "tower" else None
         peak = PEAK_F16_MATRIX_TFLOPS if a.dtype == "f16" else PEAK_F32_MATRIX_TFLOPS
         tree = tree_roofline(S, 10, sims, evals, depth, cs1.value - cs0.value, cms.value + ams.value, nw.value)
         if tree:
             tree["share_of_step"] = round((cms.value + ams.value) / (dt * 1e3), 4)
+        games_stored = tally["games"]
+        mean_len = tally["positions"] / games_stored if games_stored else None
+        info = mem.info()
+        net_name = (f"{a.blocks}-block x {a.filters}-filter tower" if a.network == "tower"
+                    else f"reference MainNetwork (RARRRARRRRAR+P, {a.filters} filters)")
         line = {
             "metric": "MCTS simulations/sec", "value": round(value, 1), "unit": "sims/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"{S}x{S} Go self-play, {a.sims} sims/move, {a.blocks}-block x {a.filters}-filter tower, "
+            "games_per_hour": round(games_stored / dt * 3600.0, 1),
+            "config": {"workload": f"{S}x{S} Go self-play, {a.sims} sims/move, {net_name}, "
                                    f"{a.games} concurrent boards per GPU", "boards_per_gpu": a.games,
                        "parallelism": f"games sharded over {world} GPU(s), no data-path collective",
-                       "step": "one move of every board (search + move selection + re-root + gather of finished games)"},
+                       "step": "one move of every board (search + move selection + record + re-root) and, for the games it "
+                               "finishes, device-side target generation, gather to rank 0 and append to the device replay store",
+                       "stagger": (f"slot g starts the warm-up g mod {period} plies into its game ({period - 1} untimed moves "
+                                   f"with 8-simulation searches, {stagger_s:.1f} s)") if period > 1 else "none: all boards start together"},
             "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(conv_tflops / peak, 4), "traffic": traffic,
                          "traffic_note": (f"HBM bytes per full-batch launch, FETCH_SIZE x2 + WRITE_SIZE (profiles/{os.path.basename(tfile)})"
@@ -221,11 +301,17 @@ def main():
                          "launches": int(nl.value), "avg_launch_ms": round(ms.value / max(1, nl.value), 4)},
             "roofline_tree": tree,
             "cpu_baseline": cpu,
+            "cpu_baseline_c1": cpu_c1,
+            "selfplay_games": {"finished_and_stored": games_stored, "finished_all_ranks": int(fin_all),
+                               "positions_stored": tally["positions"], "mean_game_length": round(mean_len, 2) if mean_len else None,
+                               "games_per_hour": round(games_stored / dt * 3600.0, 1),
+                               "games_per_hour_from_step_time": (round(world * a.games * 3600.0 / (dt / a.steps * mean_len), 1)
+                                                                 if mean_len else None),
+                               "dropped_arena_overflow": int(drop_all),
+                               "replay_entries": info["entries"], "consumer": "DeviceReplayMemory on rank 0 (tg_replay_append_dev)"},
             "extra": {"leaves_per_s": round(evals_all / dt, 1), "mean_depth": round(depth_all / max(1.0, sims_all), 3),
-                      "net_tflops_end_to_end": round(evals_all * fpl / dt / 1e12, 2),
-                      "games_per_hour_est": round(world * a.games * 3600.0 / (dt / a.steps * cfg.max_step), 1),
-                      "finished_games_gathered": gathered, "tree_errors": st1["errors"],
-                      "arena_high_water_slots": st1["max_slots"]},
+                      "net_tflops_end_to_end": round(evals_all * fpl / dt / 1e12, 2) if fpl else None,
+                      "tree_errors": st1["errors"], "arena_high_water_slots": st1["max_slots"]},
         }
         print(json.dumps(line))
     if world > 1:

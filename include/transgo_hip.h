@@ -55,7 +55,9 @@ typedef struct tg_config {
     int32_t net_filters;        /* channels F (multiple of 32) */
     int32_t device;             /* HIP device ordinal */
     int32_t net_precision;      /* 0 = f32 network (default); 1 = fp16 weights/activations, f32 accumulate (BASELINE config 5) */
-    int32_t reserved[7];
+    int32_t record_games;       /* 1 (default): every game's move record -- env.encode(root) bit-packed, raw visit counts, side to
+                                   move; the three Python lists of self_play.py:917-926 -- is kept in HBM for tg_sp_harvest */
+    int32_t reserved[6];
 } tg_config;
 
 void tg_config_default(tg_config* cfg);
@@ -147,9 +149,35 @@ int tg_sp_root_info(tg_ctx* ctx, int32_t* visits /*[G][A]*/, int32_t* root_n, in
 /* One random_sample() from each game's stream: the draw inside np.random.choice(A, p=) (self_play.py:683). */
 int tg_sp_draw_uniform(tg_ctx* ctx, double* u /*[G]*/, const uint8_t* mask);
 int tg_sp_rng_state(tg_ctx* ctx, int game, tg_mt19937* out);
-/* update_with_action (self_play.py:857-872) for every unfinished game; done[g] = game over.  Leaves a root batch
- * pending for the games whose new root was not yet expanded. */
+/* update_with_action (self_play.py:857-872) for every unfinished game; done[g] = 1 game over, 2 the game is parked in
+ * error (tree arena overflow; see tg_sp_game_errors), 0 otherwise.  With cfg.record_games the move's record entry is
+ * written first (self_play.py:917-926).  Leaves a root batch pending for the games whose new root was not yet expanded. */
 int tg_sp_play(tg_ctx* ctx, const int32_t* actions /*[G]*/, uint8_t* done /*[G]*/);
+/* A game whose tree outgrows its arena (cfg.arena_slots) is parked: it takes no further part in searches, tg_sp_play reports
+ * 2 for it, every other game is unaffected, and tg_sp_reset with its mask bit starts a new game in the slot.  n_errors = games
+ * parked right now (as of the last collect/play; no device round trip when err is NULL); err[g] = 0 or a bit set (1 arena,
+ * 2 path depth, 4 action not among the root's children). */
+int tg_sp_game_errors(tg_ctx* ctx, int32_t* n_errors, int32_t* err /*[G] or NULL*/);
+/* The reference keeps the searched tree in unbounded Python memory (tree reuse, self_play.py:860); here a re-rooted tree may
+ * keep at most arena_slots minus the room of one full search.  When the kept sub-tree is larger (very peaked policies, many
+ * moves in a row) its deepest blocks are dropped: those nodes keep their statistics and become unexpanded leaves again.
+ * blocks = how many were dropped so far over all games (0 = every search so far equals the reference's). */
+int tg_sp_tree_truncations(tg_ctx* ctx, uint64_t* blocks);
+
+/* ---- finished games -> training positions, on the device (self_play.py:929-967) ------------------------------------------
+ * Games the LAST tg_sp_play finished, in ascending slot order, and the number of recorded positions (= moves) they hold. */
+int tg_sp_finished(tg_ctx* ctx, int32_t* n_games, int32_t* n_positions);
+/* Their positions as one position-major batch, game after game in that order, plies ascending -- the arrays
+ * tg_replay_append(_dev) takes: obs_bits u32[n_positions][ceil(C*S*S/32)] (env.encode bit-packed, bit i = plane-major flat
+ * index i), counts i32[n_positions][A] (raw visit counts; pi = counts with 1 -> 0, / sum, self_play.py:666-671), z
+ * f32[n_positions] (+1 mover == winner else -1, :931-934), own i8[n_positions][S*S] (territory from the mover's side,
+ * :938-940), player u8[n_positions] (may be NULL).  device_out != 0: those five are pointers into this GPU's memory (e.g. the
+ * payload tensors of an RCCL gather) and nothing bulky crosses PCIe.  Per-game tables are host arrays and may be NULL:
+ * slot / n_moves / winner (1 black, 2 white, environment.py:118-119) / score (getScore, go_env.cc:126-130) [n_games], terr
+ * i8[n_games][S*S] (getTerritory, +1 black / 0 / -1 white).  Call before tg_sp_reset restarts the slots.  The 8-fold
+ * augmentation (self_play.py:943-965) is applied by the consumer (tg_replay_sample; transgo_amd.self_play.game_targets). */
+int tg_sp_harvest(tg_ctx* ctx, uint32_t* obs_bits, int32_t* counts, float* z, int8_t* own, uint8_t* player, int device_out,
+                  int32_t* slot, int32_t* n_moves, int32_t* winner, float* score, int8_t* terr);
 /* getScoreAndTerritory / getWinner of the current root position (self_play.py:932-937). */
 int tg_sp_final(tg_ctx* ctx, float* score /*[G]*/, float* terr /*[G][S*S]*/, int32_t* winner /*[G]*/);
 /* Aggregate counters: completed simulations, evaluated leaves, summed selection depth, RNG words drawn by tie
@@ -190,6 +218,8 @@ int tg_replay_create(tg_ctx* ctx, int capacity_positions, tg_replay** out);
 void tg_replay_destroy(tg_replay* rp);
 int tg_replay_append(tg_replay* rp, const uint32_t* obs_bits /*[n][ceil(C*S*S/32)]*/, const int32_t* counts /*[n][A]*/,
                      const float* z /*[n]*/, const int8_t* own /*[n][S*S]*/, int n);
+/* The same with the four arrays in this GPU's memory (tg_sp_harvest with device_out, or what an RCCL gather delivered). */
+int tg_replay_append_dev(tg_replay* rp, const uint32_t* obs_bits, const int32_t* counts, const float* z, const int8_t* own, int n);
 int tg_replay_info(const tg_replay* rp, long long* entries, long long* index, int* full);
 int tg_replay_sample(tg_replay* rp, const long long* entry /*[B]*/, int B, float* state /*[B][C][S][S]*/, float* pi /*[B][A]*/,
                      float* z /*[B]*/, float* own /*[B][S*S]*/, int device_out);

@@ -41,4 +41,11 @@ def sharp(obs):
     return _finish(np.left_shift(1, h % 11), v)
 
 
-BY_NAME = {"flat": flat, "sharp": sharp}
+def spike(obs):
+    """Almost all prior mass on the point(s) with the largest plane hash -- the shape of a trained, confident policy: visits
+    pile onto one child, so nearly the whole tree is inherited on every re-rooting (arena sizing / truncation tests)."""
+    h, v = _hash_planes(np.asarray(obs))
+    return _finish(np.where(h == h.max(axis=1, keepdims=True), 1 << 16, 1), v)
+
+
+BY_NAME = {"flat": flat, "sharp": sharp, "spike": spike}

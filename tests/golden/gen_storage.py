@@ -31,6 +31,25 @@ def scenario(ReplayCls, StorageCls, cfg):
     out["infos"] = np.array(infos); out["samples"] = np.array(samples)
     sv = mem.save()
     out["save_meta"] = np.array([sv["buffer_capacity"], sv["index"], int(sv["full"]), sv["save_len"]])
+    # the pickled layout other tools (and the other implementation) see: data is a 2-D object array, one column per tuple field
+    out["save_data_shape"] = np.array(np.shape(sv["data"]))
+    out["save_z"] = np.array([float(row[2]) for row in sv["data"]])
+    out["save_obs00"] = np.array([float(row[0][0, 0, 0]) for row in sv["data"]])
+    cfg.buffer_size = 10
+    part = ReplayCls(cfg)                                           # part-filled: the unfilled rows are blank tuples
+    for i in range(4):
+        part.append(*tup(i))
+    pv = part.save()
+    out["partial_shape"] = np.array(np.shape(pv["data"]))
+    out["partial_z"] = np.array([float(row[2]) for row in pv["data"]])
+    out["partial_pi_len"] = np.array([len(row[1]) for row in pv["data"]])
+    # a save() dict spelt out in that layout by hand loads into the class
+    hand = {"buffer_capacity": 10, "index": 3, "full": False, "save_len": 3,
+            "data": np.array([tup(20), tup(21), tup(22)], dtype=object)}
+    out["hand_shape"] = np.array(hand["data"].shape)
+    tgt = ReplayCls(cfg)
+    tgt.load(hand)
+    out["hand_loaded_z"] = np.array([float(row[2]) for row in tgt.data[:3]])
     cfg.buffer_size = 120
     big = ReplayCls(cfg)
     fulls = []

@@ -1,0 +1,175 @@
+"""The finished-game path that lives on the device: the per-move record written by tg_sp_play, tg_sp_harvest's target
+generation (self_play.py:929-967), the device -> device append into the replay store, the multi-rank actor loop -- against the
+same material assembled on the host the way the reference's self-play loop does (self_play.py:917-926: append root observation,
+pi and player per move; :932-940 score, winner, territory at the end)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import evaluators
+
+pytestmark = pytest.mark.gpu
+
+
+def _play_and_assemble(eng, seeds, moves):
+    """Drive the engine move by move, keeping the reference's three per-game lists on the host from root_info; returns
+    ({slot: (obs list, visits list, players list, winner, territory, score)} for finished games, [harvest batches])."""
+    G = eng.G
+    lists = [([], [], []) for _ in range(G)]
+    finished, batches = {}, []
+    eng.reset(seeds)
+    for _ in range(moves):
+        live = ~eng.finished
+        eng.search()
+        vis, rn, pl, st, ob = eng.root_info()
+        acts, pis = eng.choose_moves(vis, st)
+        for g in np.flatnonzero(live):
+            lists[g][0].append(ob[g].copy()); lists[g][1].append(vis[g].copy()); lists[g][2].append(int(pl[g]))
+        done = eng.play(acts)
+        if done.any():
+            score, terr, win = eng.final()
+            for g in np.flatnonzero(done & live):
+                finished[int(g)] = lists[g] + (int(win[g]), terr[g].copy(), float(score[g]))
+            batches.append((eng.harvest(device=False, seeds=seeds), eng.harvest(device=True, seeds=seeds)))
+        if eng.finished.all():
+            break
+    return finished, batches
+
+
+@pytest.mark.parametrize("S,G,sims,max_step", [(9, 7, 24, 14), (19, 3, 12, 9)])
+def test_device_records_equal_host_assembled_records(S, G, sims, max_step):
+    from transgo_amd.engine import SelfPlayEngine
+    from transgo_amd.self_play import game_targets
+    eng = SelfPlayEngine(G, board_size=S, num_simulation=sims, max_step=max_step, evaluator=evaluators.sharp)
+    seeds = np.arange(40, 40 + G).astype(np.uint32)
+    finished, batches = _play_and_assemble(eng, seeds, max_step + 1)
+    assert len(finished) == G and batches
+    seen = set()
+    for host, dev in batches:
+        assert not host.on_device and dev.on_device and host.nbytes == dev.nbytes
+        assert np.array_equal(host.buf, dev.to_host().buf)           # the device batch is byte-identical to the host one
+        slots = host.view("slot")
+        assert list(slots) == sorted(slots)
+        recs = host.records()
+        tup = host.targets()
+        o = 0
+        for i, g in enumerate(slots):
+            obs, vis, pls, win, terr, score = finished[int(g)]
+            r = recs[i]
+            assert r.seed == int(seeds[g]) and r.winner == win and r.score == score and np.array_equal(r.territory, terr)
+            assert r.players == pls and len(r.observations) == len(obs) == host.view("n_moves")[i]
+            assert all(np.array_equal(a, b) for a, b in zip(r.observations, obs))
+            assert all(np.array_equal(a, b) for a, b in zip(r.visits, vis))
+            want = game_targets(obs, r.pis, pls, win, terr, S)       # the reference's appends for this game
+            got = tup[o:o + len(want)]
+            assert all(all(np.array_equal(p, q) for p, q in zip(x, y)) for x, y in zip(got, want))
+            o += len(want)
+            seen.add(int(g))
+        assert o == len(tup)
+    assert seen == set(range(G))
+    eng.close()
+
+
+def test_harvest_feeds_the_device_replay_store_without_the_host():
+    """BatchedSelfPlay.advance(device=True) -> DeviceReplayMemory.append_harvest (tg_replay_append_dev): sampled entries equal
+    the reference data path (8 augmented tuples per position appended in order, np.stack, float32; trainer.py:46-54)."""
+    import torch
+    from transgo_amd.configure import Config
+    from transgo_amd.replay_buffer import DeviceReplayMemory, ReplayMemory_Random
+    from transgo_amd.self_play import BatchedSelfPlay
+    cfg = Config(num_simulation=16, max_step=10, buffer_size=8 * 4096)
+    sp = BatchedSelfPlay(cfg, 12, evaluator=evaluators.flat)
+    dev = DeviceReplayMemory(cfg, capacity_positions=4096)
+    host = ReplayMemory_Random(cfg)
+    games = 0
+    for _ in range(23):                                              # two generations of games and a bit
+        h = sp.advance(device=True)
+        if h is None:
+            continue
+        assert h.on_device
+        dev.append_harvest(h)
+        for t in h.targets():
+            host.append(*t)
+        games += h.n_games
+    assert games == 24 and sp.games_finished == 24 and dev.info()["entries"] == host.info()["index"] == 24 * 10 * 8
+    idx = np.random.RandomState(0).choice(host.info()["index"], 300, replace=False)
+    s, p, z, o = map(np.stack, zip(*host.data[idx]))                 # trainer.py:49
+    s, p, z, o = (torch.FloatTensor(a).numpy() for a in (s, p, z, o))
+    ds, dp, dz, do = dev.sample_entries(idx)
+    assert np.array_equal(ds, s) and np.array_equal(dp, p) and np.array_equal(dz, z) and np.array_equal(do, o)
+    dev.close()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _actor_worker(rank, world, port, q, backend):
+    """One rank of the actor loop: its own shard of games on the GPU, finished games gathered to rank 0, only rank 0 appends
+    and counts.  backend gloo = both ranks on GPU 0 (payloads staged through the host); nccl = one GPU per rank."""
+    import torch
+    import torch.distributed as dist
+    from transgo_amd.configure import Config
+    from transgo_amd.replay_buffer import DeviceReplayMemory, ReplayMemory_Random
+    from transgo_amd.self_play import SelfPlay
+    from transgo_amd.shared_storage import SharedStorage
+    gpu = rank if backend == "nccl" else 0
+    if backend == "nccl":
+        torch.cuda.set_device(gpu)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", gpu))
+    else:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    cfg = Config(num_simulation=8, max_step=5, buffer_size=8 * 1024)
+    G = 3 + rank                                                     # ragged shards
+    actor = SelfPlay(cfg, n_games=G, device=gpu, rank=rank, world=world, evaluator=evaluators.flat)
+    st = mem = None
+    if rank == 0:
+        st = SharedStorage({"weights": None, "now_play_steps": 0, "now_play_games": 0, "now_train_steps": 10 ** 9,
+                            "train_play_ratio": 0.075, "adjust_train_play_ratio": True, "game_total_num": 1e8,
+                            "adjust_lr": False, "learn_rate": 1e-4}, cfg)
+        mem = DeviceReplayMemory(cfg, capacity_positions=1024, device=gpu) if backend == "nccl" else ReplayMemory_Random(cfg)
+    actor.continuous_self_play(st, mem, max_moves=11)                # 2 full generations (5 moves each) + 1 move
+    out = {"rank": rank, "finished_local": actor.worker.games_finished, "G": G}
+    if rank == 0:
+        info = mem.info()
+        out.update(steps=st.get_info("now_play_steps"), games=st.get_info("now_play_games"),
+                   entries=info.get("entries", info["index"]))
+    q.put(out)
+    dist.destroy_process_group()
+
+
+def _run_actor_ranks(backend):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_actor_worker, args=(r, 2, port, q, backend)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda d: d["rank"])
+    [p.join(120) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    r0, r1 = res
+    assert r0["finished_local"] == 2 * 3 and r1["finished_local"] == 2 * 4
+    assert r0["games"] == 14                                          # every rank's finished games reached the owner
+    assert r0["entries"] == 14 * 5 * 8                                # 5 positions per game, 8 reference entries per position
+    # now_play_steps: the owner adds G_owner * world per step (shards are equal-sized in production; ragged only here)
+    assert r0["steps"] == 11 * 3 * 2
+    return res
+
+
+def test_actor_loop_two_ranks_gloo_on_one_gpu():
+    """SelfPlay.continuous_self_play with torch.distributed initialised: the ACTOR path, not just the
+    gather helper -- two processes share GPU 0, gloo carries the payloads."""
+    _run_actor_ranks("gloo")
+
+
+def test_actor_loop_two_ranks_rccl():
+    """The same over RCCL with device-resident payloads end to end (harvest in HBM -> send/recv -> tg_replay_append_dev).
+    Needs two GPUs; skipped on the one-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    _run_actor_ranks("nccl")

@@ -57,7 +57,8 @@ def test_reference_full_games(golden_dir, tag):
     assert eng.stats()["errors"] == 0
 
 
-@pytest.mark.parametrize("tag,full", [("sharp_s21_n48", True), ("flat_s22_n24", True), ("sharp_s23_n160", False)])
+@pytest.mark.parametrize("tag,full", [("sharp_s21_n48", True), ("flat_s22_n24", True), ("sharp_s23_n160", False),
+                                      ("sharp_s24_n800", False)])     # the last: BASELINE configs[3]'s 800 simulations/move
 def test_reference_19x19_search(golden_dir, tag, full):
     """Board size 19 against vectors recorded from the reference WP_MCTS on a 19x19 build of its engine
     (tests/golden/gen_search19.py): visit counts, moves, pi, RNG position per move; final score / territory of full games."""
@@ -159,17 +160,45 @@ def test_policy_evaluate_runs_matches_and_reports():
         assert st.get_info("evaluate_score") == 100
 
 
-def test_arena_overflow_is_reported_not_fatal():
-    """A deliberately tiny tree arena: the engine must flag the games, return TG_ERR_ARENA and stay usable (no out-of-bounds
-    write, no endless search)."""
-    from transgo_amd._lib import TransgoError
+def test_arena_overflow_parks_the_game_and_the_slot_restarts():
+    """A deliberately tiny tree arena: the overflowing games are parked (no out-of-bounds write, no endless search, no
+    exception), tg_sp_play reports them, the other entry points stay usable, and resetting the slots starts new games."""
     from transgo_amd.engine import SelfPlayEngine
     eng = SelfPlayEngine(4, num_simulation=64, evaluator=evaluators.flat, arena_slots=4 * 84 + 16)
     eng.reset(np.arange(4))
-    with pytest.raises(TransgoError):
-        eng.search()
-    assert eng.stats()["errors"] >= 1
+    eng.search()                                               # the search ends: parked games are not active
+    err = eng.game_errors()
+    assert (err & 1).all() and eng.stats()["errors"] == 4
+    vis, st = eng.root_visits()
+    done = eng.play(eng.choose_moves(vis, st)[0])
+    assert not done.any() and eng.errored.all() and eng.finished.all()
+    assert eng.harvest() is None                               # parked games are not finished games
+    eng.reset(np.arange(10, 14), eng.errored)                  # new games in the same slots
+    assert eng.stats()["errors"] == 0 and not eng.errored.any()
+    eng.search(num_simulation=2)                               # 2 simulations fit even this arena
+    assert eng.stats()["errors"] == 0
     eng.close()
-    eng2 = SelfPlayEngine(2, num_simulation=8, evaluator=evaluators.flat)      # a fresh context still works
-    eng2.reset([1, 2]); eng2.search()
-    assert eng2.stats()["errors"] == 0
+
+
+def test_peaked_policy_full_games_stay_inside_the_default_arena():
+    """a confident policy keeps most of the tree on every re-rooting (kept tree ~ sims / (1 - r) blocks).  With the
+    default arena the engine must get through whole games without parking any: the re-rooting copy is bounded (deepest blocks
+    dropped first, counted), everything else as usual.  Also checks the bound is actually exercised by this evaluator."""
+    from transgo_amd.configure import Config
+    from transgo_amd.self_play import BatchedSelfPlay
+    cfg = Config(num_simulation=96, max_step=60)
+    sp = BatchedSelfPlay(cfg, 8, evaluator=evaluators.spike)
+    fin = []
+    for _ in range(64):
+        fin += sp.step()
+    st = sp.engine.stats()
+    print("peaked policy: arena high-water", st["max_slots"], "truncated blocks", st["truncated_blocks"], "finished", len(fin))
+    assert st["errors"] == 0 and sp.games_dropped == 0 and len(fin) >= 8
+    assert all(len(r.players) == len(r.pis) >= 1 for r in fin)
+    # same evaluator, an arena four times smaller than the default: the bound is hit and handled, still no parked game
+    sp2 = BatchedSelfPlay(cfg, 8, evaluator=evaluators.spike, arena_slots=((3 * 96 + 256) * 84) // 4)
+    for _ in range(40):
+        sp2.step()
+    st2 = sp2.engine.stats()
+    print("quarter arena: high-water", st2["max_slots"], "truncated blocks", st2["truncated_blocks"])
+    assert st2["errors"] == 0 and sp2.games_dropped == 0

@@ -90,29 +90,41 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+def _fake_games(rng, sizes, seed0=0):
+    recs = []
+    for k, n in enumerate(sizes):
+        r = GameRecord(seed0 + k)
+        for m in range(n):
+            r.observations.append((rng.rand(10, 9, 9) < 0.3).astype(np.float32))
+            v = rng.randint(0, 9, 82).astype(np.int32); v[5] = 7; v[3] = 1; r.visits.append(v)
+            c = np.where(v == 1, 0, v); r.pis.append(c / c.sum()); r.players.append(1 + m % 2)
+        r.winner = 1 + k % 2; r.territory = rng.randint(-1, 2, 81).astype(np.float32); r.score = float(k) - 0.5
+        recs.append(r)
+    return recs
+
+
+def _summary(recs):
+    return [(len(g.players), g.winner, g.seed, float(np.sum(g.territory)), float(sum(p.sum() for p in g.pis)),
+             float(sum(o.sum() for o in g.observations)), int(sum(int(v.sum()) for v in g.visits))) for g in recs]
+
+
 def _gather_worker(rank, world, port, q):
     import torch.distributed as dist
-    from transgo_amd.distributed import broadcast_weights, gather_records
+    from transgo_amd import records
+    from transgo_amd.distributed import broadcast_weights, gather_harvest
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     rng = np.random.RandomState(rank)
-    recs = []
-    for k in range(rank + 1):                            # rank 0: 1 game, rank 1: 2 games (ragged)
-        r = GameRecord(100 * rank + k)
-        for m in range(3 + k):
-            r.observations.append((rng.rand(10, 9, 9) < 0.3).astype(np.float32))
-            v = rng.randint(0, 9, 82).astype(np.int32); v[5] = 7; r.visits.append(v)
-            c = np.where(v == 1, 0, v); r.pis.append(c / c.sum()); r.players.append(1 + m % 2)
-        r.winner = 1 + rank % 2; r.territory = rng.randint(-1, 2, 81).astype(np.float32)
-        recs.append(r)
-    got = gather_records(recs, 9, 10, dst=0)
-    empty = gather_records([], 9, 10, dst=0)             # nothing finished anywhere: no payload exchange
+    recs = _fake_games(rng, [3 + k for k in range(rank + 1)], seed0=100 * rank)     # rank 0: 1 game, rank 1: 2 games (ragged)
+    h = records.from_records(recs, 9, 10)
+    got = gather_harvest(h, 9, 10, dst=0)
+    empty = gather_harvest(None, 9, 10, dst=0)             # nothing finished anywhere: no payload exchange
+    only1 = gather_harvest(h if rank == 1 else None, 9, 10, dst=0)                  # the owner itself has nothing to add
     blob = np.arange(10, dtype=np.float32) * (rank + 1)
     blob = broadcast_weights(blob, src=0)
-    out = [(len(g.players), g.winner, float(np.sum(g.territory)), float(sum(p.sum() for p in g.pis)),
-            float(sum(o.sum() for o in g.observations))) for g in got]
-    mine = [(len(g.players), g.winner, float(np.sum(g.territory)), float(sum(p.sum() for p in g.pis)),
-             float(sum(o.sum() for o in g.observations))) for g in recs]
-    q.put((rank, out, mine, len(empty), blob.tolist()))
+    out = [x for hb in got for x in _summary(hb.records())]
+    out1 = [x for hb in only1 for x in _summary(hb.records())]
+    nbytes = [hb.nbytes for hb in got]
+    q.put((rank, out, _summary(recs), len(empty), blob.tolist(), out1, nbytes, h.nbytes))
     dist.destroy_process_group()
 
 
@@ -125,10 +137,82 @@ def test_gather_two_ranks_gloo():
     [p.start() for p in ps]
     res = sorted(q.get(timeout=120) for _ in range(2))
     [p.join(60) for p in ps]
-    (r0, out0, mine0, e0, b0), (r1, out1, mine1, e1, b1) = res
-    assert out1 == [] and e0 == 0 and e1 == 0
+    (r0, out0, mine0, e0, b0, o10, nb0, my0), (r1, out1, mine1, e1, b1, o11, nb1, my1) = res
+    assert out1 == [] and e0 == 0 and e1 == 0 and o11 == []
     assert out0 == mine0 + mine1                          # rank order, exact payloads (pi recomputed from counts)
+    assert o10 == mine1
+    assert nb0 == [my0, my1] and my1 > my0                # every payload travels at its own length, not padded to the largest
     assert b0 == b1 == list(np.arange(10, dtype=np.float32))
+
+
+def test_harvest_batch_equals_per_game_targets(tmp_path):
+    """records.Harvest.targets() (whole-batch rot90/flip) == game_targets (the literal per-game form, pinned above against the
+    reference's own appends), tuple for tuple; records() is the inverse of from_records()."""
+    from transgo_amd import records
+    rng = np.random.RandomState(4)
+    recs = _fake_games(rng, [4, 1, 7], seed0=9)
+    h = records.from_records(recs, 9, 10)
+    assert h.n_games == 3 and h.n_positions == 12 and not h.on_device
+    back = h.records()
+    assert _summary(back) == _summary(recs)
+    for a, b in zip(back, recs):
+        assert all(np.array_equal(x, y) for x, y in zip(a.observations, b.observations))
+        assert all(np.array_equal(x, y) for x, y in zip(a.pis, b.pis)) and a.players == b.players
+    want = [t for r in recs for t in game_targets(r.observations, r.pis, r.players, r.winner, r.territory, 9)]
+    got = h.targets()
+    assert len(got) == len(want) == 8 * 12
+    for x, y in zip(got, want):
+        assert x[0].dtype == y[0].dtype == np.float32 and x[1].dtype == y[1].dtype == np.float64 and x[3].dtype == y[3].dtype
+        assert all(np.array_equal(p, q) for p, q in zip(x, y))
+
+
+def test_default_game_seeds_never_collide():
+    """with 1000*rank + g two ranks shared seeds as soon as a rank held more than 1000 boards."""
+    from transgo_amd.self_play import default_seed
+    world, G = 8, 4096
+    seen = set()
+    for k in range(3):
+        for rank in range(world):
+            s = {default_seed(rank, world, G, g, k) for g in range(G)}
+            assert len(s) == G and not (s & seen)
+            seen |= s
+    assert default_seed(0, 8, 4096, 17, 0) == 17 and max(seen) < 2 ** 32
+    with pytest.raises(OverflowError):
+        default_seed(7, 8, 4096, 0, 2 ** 20)
+
+
+def test_replay_buffer_pickled_layout_is_the_references(golden_dir):
+    """ReplayMemory_Random.data is the reference's 2-D (capacity, 4) object array (replay_buffer.py:21-27), so save() / load()
+    dicts are interchangeable with the reference's: the layout facts below were recorded from the reference class itself
+    (tests/golden/gen_storage.py), including a part-filled buffer (blank rows) and a hand-built (N, 4) dict loaded back."""
+    want = _load(golden_dir, "storage.npz")
+    cfg = Config(buffer_size=50)
+    mem = ReplayMemory_Random(cfg)
+    assert mem.data.shape == (50, 4) and mem.data.dtype == object
+    assert list(want["save_data_shape"]) == [50, 4] and list(want["partial_shape"]) == [10, 4] and list(want["hand_shape"]) == [3, 4]
+    # a dict in the reference's layout loads; rows come back as the four fields
+    tup = lambda i: (np.full((10, 9, 9), i, np.float32), np.full(82, 1.0 / 82), float(i), np.full(81, -float(i)))
+    hand = {"buffer_capacity": 10, "index": 3, "full": False, "save_len": 3, "data": np.array([tup(20), tup(21), tup(22)], dtype=object)}
+    assert hand["data"].shape == (3, 4)
+    mem.load(hand)
+    assert [float(r[2]) for r in mem.data[:3]] == list(want["hand_loaded_z"]) and mem.index == 3
+    s, p, z, o = map(np.stack, zip(*mem.sample(2)))      # trainer.py:49 still stacks rows
+    assert s.shape == (2, 10, 9, 9) and p.shape == (2, 82) and o.shape == (2, 81)
+
+
+def test_add_info_equals_repeated_increments():
+    """SharedStorage.add_info(key, n) == n times set_info(key) (shared_storage.py:21-43 with both schedules)."""
+    rng = np.random.RandomState(1)
+    for trial in range(30):
+        base = {"now_play_steps": int(rng.randint(0, 20)), "now_play_games": int(rng.randint(0, 3)), "learn_rate": 6.5e-5,
+                "adjust_lr": bool(trial % 3), "train_play_ratio": 0.075, "adjust_train_play_ratio": bool(trial % 2)}
+        a, b = SharedStorage(base, Config()), SharedStorage(base, Config())
+        for key in ("now_play_steps", "now_play_games", "now_play_steps"):
+            n = int(rng.randint(0, 5000))
+            for _ in range(n):
+                a.set_info(key)
+            b.add_info(key, n)
+            assert a.current_checkpoint == b.current_checkpoint, (trial, key, n)
 
 
 def test_vectorised_move_selection_equals_per_game_form():
@@ -167,7 +251,7 @@ def test_packed_replay_file_roundtrip(tmp_path):
         recs.append(r)
     path = str(tmp_path / "replay.tgrp")
     save_packed(path, recs, 9, 10)
-    assert os.path.getsize(path) < 3 * 8 * 450 + 400
+    assert os.path.getsize(path) < 18 * 560 + 3 * 120 + 64           # ~0.52 KB per position + the per-game tables
     back = load_packed(path)
     assert len(back) == 3 and [len(r.players) for r in back] == [5, 6, 7]
     cfg = Config(buffer_size=1024)

@@ -15,7 +15,7 @@ class TgConfig(ctypes.Structure):
                 ("parallel_readouts", ctypes.c_int32), ("wu_loss", ctypes.c_int32), ("c_puct1", ctypes.c_double),
                 ("c_puct2", ctypes.c_double), ("arena_slots", ctypes.c_int32), ("net_blocks", ctypes.c_int32),
                 ("net_filters", ctypes.c_int32), ("device", ctypes.c_int32), ("net_precision", ctypes.c_int32),
-                ("reserved", ctypes.c_int32 * 7)]
+                ("record_games", ctypes.c_int32), ("reserved", ctypes.c_int32 * 6)]
 
 
 class TgMt19937(ctypes.Structure):
@@ -59,6 +59,10 @@ SIGNATURES = {
     "tg_sp_rng_state": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(TgMt19937)]),
     "tg_sp_play": (ctypes.c_int, [_vp, _vp, _vp]),
     "tg_sp_final": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "tg_sp_game_errors": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _vp]),
+    "tg_sp_tree_truncations": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
+    "tg_sp_finished": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
+    "tg_sp_harvest": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     "tg_sp_stats": (ctypes.c_int, [_vp] + [ctypes.POINTER(ctypes.c_uint64)] * 4 + [ctypes.POINTER(ctypes.c_int32)] * 2),
     "tg_net_blob_floats": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "tg_net_load": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_int]),
@@ -73,6 +77,7 @@ SIGNATURES = {
     "tg_replay_create": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "tg_replay_destroy": (None, [_vp]),
     "tg_replay_append": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int]),
+    "tg_replay_append_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int]),
     "tg_replay_info": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_int)]),
     "tg_replay_sample": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_int]),
     "tg_host_mt_seed": (None, [ctypes.POINTER(TgMt19937), ctypes.c_uint32]),

@@ -374,14 +374,13 @@ template <int S> __device__ __forceinline__ void legal_words(const BoardWave<S>&
     for (int k = 0; k < Geo<S>::NW; ++k) out[k] = ballot64(bw.pt[k] < Geo<S>::P && bw.legal(k, st, st.next_player));
 }
 
-// board_feature.cc:213-253 encode9/10/13 -> f32 planes [C][P] at `out` (plane-major, like the reference).
+// board_feature.cc:213-253 encode9/10/13 as one bit mask per owned point: bit c of m[k] = plane c at point pt[k].
 // Position must be loaded + analysed.  Clobbers L->aux.
-template <int S> __device__ void encode_planes(BoardWave<S>& bw, const BoardState<S>& st, const RulesCfg& cfg, float* out) {
+template <int S> __device__ void encode_mask(BoardWave<S>& bw, const BoardState<S>& st, const RulesCfg& cfg, uint32_t* m) {
     using G = Geo<S>;
     const int C = cfg.encode_dim, me = st.next_player, op = 3 - me;
     int pl_h2 = -1, pl_ko = 7, pl_eye = 8, pl_oeye = -1, pl_live = (C == 9) ? -1 : 9, pl_olive = -1;
     if (C == 13) { pl_h2 = 7; pl_ko = 8; pl_eye = 9; pl_oeye = 10; pl_live = 11; pl_olive = 12; }
-    // plane indices (runtime C): static arrays below are only ever indexed with compile-time constants
     bool live_me[G::NW], live_op[G::NW];
 #pragma unroll
     for (int k = 0; k < G::NW; ++k) { live_me[k] = false; live_op[k] = false; }
@@ -416,21 +415,59 @@ template <int S> __device__ void encode_planes(BoardWave<S>& bw, const BoardStat
 #pragma unroll
     for (int k = 0; k < G::NW; ++k) {
         const int p = bw.pt[k];
-        if (p >= G::P) continue;
-        const bool mine = bw.col[k] == me, theirs = bw.col[k] == op;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            out[j * G::P + p] = (mine && cls[k] == j) ? 1.f : 0.f;
-            out[(3 + j) * G::P + p] = (theirs && cls[k] == j) ? 1.f : 0.f;
+        uint32_t v = 0;
+        if (p < G::P) {
+            const bool mine = bw.col[k] == me, theirs = bw.col[k] == op;
+            if (mine && cls[k] >= 0) v |= 1u << cls[k];
+            if (theirs && cls[k] >= 0) v |= 1u << (3 + cls[k]);
+            if (st.last_move1 == p) v |= 1u << 6;                       // board_feature.cc:92-100
+            if (pl_h2 >= 0 && st.last_move2 == p) v |= 1u << pl_h2;
+            if (kosu[k]) v |= 1u << pl_ko;
+            if (eye_me[k]) v |= 1u << pl_eye;
+            if (pl_oeye >= 0 && eye_op[k]) v |= 1u << pl_oeye;
+            if (pl_live >= 0 && live_me[k]) v |= 1u << pl_live;
+            if (pl_olive >= 0 && live_op[k]) v |= 1u << pl_olive;
         }
-        out[6 * G::P + p] = (st.last_move1 == p) ? 1.f : 0.f;          // board_feature.cc:92-100
-        if (pl_h2 >= 0) out[pl_h2 * G::P + p] = (st.last_move2 == p) ? 1.f : 0.f;
-        out[pl_ko * G::P + p] = kosu[k] ? 1.f : 0.f;
-        out[pl_eye * G::P + p] = eye_me[k] ? 1.f : 0.f;
-        if (pl_oeye >= 0) out[pl_oeye * G::P + p] = eye_op[k] ? 1.f : 0.f;
-        if (pl_live >= 0) out[pl_live * G::P + p] = live_me[k] ? 1.f : 0.f;
-        if (pl_olive >= 0) out[pl_olive * G::P + p] = live_op[k] ? 1.f : 0.f;
+        m[k] = v;
     }
+}
+
+// -> f32 planes [C][P] at `out` (plane-major, like the reference's Encode, go_env.cc:96-115).
+template <int S> __device__ void encode_planes(BoardWave<S>& bw, const BoardState<S>& st, const RulesCfg& cfg, float* out) {
+    using G = Geo<S>;
+    uint32_t m[G::NW];
+    encode_mask(bw, st, cfg, m);
+    const int C = cfg.encode_dim;
+#pragma unroll
+    for (int k = 0; k < G::NW; ++k) {
+        const int p = bw.pt[k];
+        if (p >= G::P) continue;
+#pragma unroll
+        for (int c = 0; c < 13; ++c)
+            if (c < C) out[c * G::P + p] = (m[k] >> c & 1u) ? 1.f : 0.f;
+    }
+}
+
+// -> the same planes bit-packed: bit i of the plane-major flat index i = c*P + p, little-endian in u32 words
+// (ceil(C*P/32) words; the layout tg_replay_append stores).  `lds` = that many words of LDS scratch.
+template <int S> __device__ void encode_bits(BoardWave<S>& bw, const BoardState<S>& st, const RulesCfg& cfg, uint32_t* lds,
+                                             uint32_t* out) {
+    using G = Geo<S>;
+    uint32_t m[G::NW];
+    encode_mask(bw, st, cfg, m);
+    const int C = cfg.encode_dim, W = (C * G::P + 31) / 32;
+    for (int i = bw.lane; i < W; i += 64) lds[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < G::NW; ++k) {
+        const int p = bw.pt[k];
+#pragma unroll
+        for (int c = 0; c < 13; ++c)
+            if (c < C && (m[k] >> c & 1u)) { const int i = c * G::P + p; atomicOr(&lds[i >> 5], 1u << (i & 31)); }
+    }
+    __syncthreads();
+    for (int i = bw.lane; i < W; i += 64) out[i] = lds[i];
+    __syncthreads();
 }
 
 // board.cc:822-958 getTTScore.  Loads colours itself.  Returns raw Tromp-Taylor area difference (0 on an empty board,

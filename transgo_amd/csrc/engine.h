@@ -23,6 +23,11 @@ struct EngineDev {
     float* policy = nullptr;        // [rows_cap][A]
     float* value = nullptr;         // [rows_cap]
     int32_t* counters = nullptr;    // [CNT_N]
+    // per-game record of the moves played so far (the observation/pi/player lists of self_play.py:917-926), ply-major per game
+    uint32_t* hist_obs = nullptr;   // [G][hist_T][obs_words]  env.encode(root) bit-packed (bit i = plane-major flat index i)
+    int32_t* hist_cnt = nullptr;    // [G][hist_T][A]          raw root visit counts
+    uint8_t* hist_pl = nullptr;     // [G][hist_T]             side to move
+    int hist_T = 0, obs_words = 0;
     SearchCfg sc;
     RulesCfg rules;
 };
@@ -36,12 +41,19 @@ struct Engine {
     bool batch_ready = false;
     bool all_reset = false;
     int last_rows = 0;
+    int n_errors = 0;                // games parked in error as of the last counter read
     size_t arena_bytes = 0;
     double* d_noise = nullptr;
     int32_t* d_i32 = nullptr;
     float* d_f32 = nullptr;
     uint8_t* d_u8 = nullptr;
-    std::vector<tg_mt19937> h_rng;
+    tg_mt19937* h_rng = nullptr;     // pinned host mirror of dev.rng; authoritative while rng_on_host (the host-side draws of a
+    bool rng_on_host = false;        // move -- choice(A, p) then the next Dirichlet -- share one round trip)
+    std::vector<int32_t> h_moves;    // moves played per game, as of the last tg_sp_play
+    std::vector<int32_t> fin_slot, fin_off;   // games finished by the last tg_sp_play (ascending slot) and their position offsets
+    int fin_positions = 0;
+    int32_t* d_fin = nullptr;        // [2][G] device copy of fin_slot / fin_off
+    DevBuf hv_obs, hv_cnt, hv_z, hv_own, hv_pl, hv_game;   // harvest staging when the caller wants host arrays
     std::vector<double> h_noise;
     std::vector<int32_t> h_nchild;
     Net* net = nullptr;

@@ -7,6 +7,7 @@
 // by values injected through tg_sp_set_eval.
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "ctx.h"
@@ -83,8 +84,9 @@ __global__ __launch_bounds__(64) void k_reset(EngineDev d, const uint8_t* mask, 
     }
     BoardWave<S> bw; bw.init(&lds);
     GameCtl c = d.ctl[g];                                             // cumulative statistics survive a reset
+    if (c.error && lane_id() == 0) atomicSub(&d.counters[CNT_ERRORS], 1);   // CNT_ERRORS = games parked in error right now
     c.cur = 0; c.free_slot = 0; c.n_target = 0; c.active = 0; c.n_paths = 0; c.need_eval = 0; c.root_row = 0;
-    c.finished = 0; c.error = 0; c.searching = 0;
+    c.finished = 0; c.error = 0; c.searching = 0; c.moves = 0;
     NodeRec* arena = arena_of<S>(d.arena, g, 0, d.sc.arena_slots);
     BoardState<S> st;
     if (states) st = states[g]; else state_reset(st);
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(64) void k_reset(EngineDev d, const uint8_t* mask, 
         arena[0] = r;
         c.cur = 0; c.free_slot = free_slot; c.need_eval = over ? 0 : 1; c.root_row = row; c.error = blk < 0 ? 1 : 0;
         c.finished = over ? 1 : 0;
+        if (c.error) atomicAdd(&d.counters[CNT_ERRORS], 1);
         d.ctl[g] = c;
         if (!over) d.row_game[row] = g;
     }
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(64) void k_collect(EngineDev d) {
         c->n_paths = npaths; c->free_slot = free_slot; c->error |= err;
         c->sims += sims; c->depth_sum += depth_sum; c->evals += evals; c->tie_draws += rng.draws; c->child_sum += child_sum;
         d.rng[g].pos = rng.pos;
-        if (err) atomicAdd(&d.counters[CNT_ERRORS], 1);
+        if (err) { atomicAdd(&d.counters[CNT_ERRORS], 1); c->searching = 0; c->active = 0; }
     }
 }
 
@@ -365,14 +368,17 @@ __global__ __launch_bounds__(64) void k_root_info(EngineDev d, int32_t* visits, 
 }
 
 // update_with_action (self_play.py:857-872) + tree compaction into the other half arena.
+// Before the root moves on, the game's record gets this move's entry -- env.encode(root) bit-packed, the raw visit counts and
+// the side to move: what self_play.py:917-926 appends to its three Python lists.
 template <int S>
-__global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions, uint8_t* done_out) {
+__global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions, uint8_t* done_out, int32_t* moves_out) {
     using G = Geo<S>;
     constexpr int HS = TreeGeo<S>::HS, NPASS = TreeGeo<S>::NPASS;
     __shared__ WaveLds<S> lds;
+    __shared__ uint32_t bits_s[(13 * G::P + 31) / 32];
     const int g = blockIdx.x, lane = lane_id();
     GameCtl* c = &d.ctl[g];
-    if (c->finished || c->error) { if (lane == 0) done_out[g] = c->finished ? 1 : 0; return; }
+    if (c->finished || c->error) { if (lane == 0) { done_out[g] = c->error ? 2 : 1; moves_out[g] = c->moves; } return; }
     const SearchCfg& sc = d.sc;
     NodeRec* old = arena_of<S>(d.arena, g, c->cur, sc.arena_slots);
     NodeRec* nw = arena_of<S>(d.arena, g, c->cur ^ 1, sc.arena_slots);
@@ -387,17 +393,35 @@ __global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions
         uint64_t m = ballot64(hit);
         if (m && idx < 0) idx = j * 64 + __ffsll((long long)m) - 1;
     }
-    if (idx < 0) { if (lane == 0) { c->error |= 4; done_out[g] = 0; atomicAdd(&d.counters[CNT_ERRORS], 1); } return; }
+    if (idx < 0) { if (lane == 0) { c->error |= 4; done_out[g] = 2; moves_out[g] = c->moves; atomicAdd(&d.counters[CNT_ERRORS], 1); } return; }
     BoardWave<S> bw; bw.init(&lds);
     BoardState<S> st = hdr_of<S>(old, rblk)->st;
+    const int t = c->moves;
+    if (d.hist_obs && t < d.hist_T) {
+        const size_t e = (size_t)g * d.hist_T + t;
+        int32_t* cnt = d.hist_cnt + e * G::A;
+        for (int a2 = lane; a2 < G::A; a2 += 64) cnt[a2] = 0;
+        __syncthreads();
+        for (int i = lane; i < nchild; i += 64) { NodeRec r = old[rblk + HS + i]; cnt[r.action] = r.n; }
+        bw.load_colors(st.bb[0], st.bb[1]);
+        bw.analyze();
+        encode_bits(bw, st, d.rules, bits_s, d.hist_obs + e * d.obs_words);
+        if (lane == 0) d.hist_pl[e] = st.next_player;
+    }
     bool ok;
     const bool done = state_step(bw, st, a, d.rules, /*check=*/false, &ok);      // self_play.py:859
     NodeRec child = old[rblk + HS + idx];
     int nfree = 1;
     if (child.flags & F_OPEN) {
-        // keep the subtree: breadth-first copy, block by block, fixing block pointers as we go
+        // keep the subtree: breadth-first copy, block by block, fixing block pointers as we go.  The reference's tree lives
+        // in unbounded Python memory; here the copy stops at `sc.keep_slots` (the arena minus the room one full search
+        // can need), shallow blocks first: a node whose block no longer fits keeps its statistics but becomes an unexpanded
+        // leaf again (it is re-evaluated on its next visit).  Never happens unless the kept tree outgrows the arena (very
+        // peaked policies, many moves in a row); counted in GameCtl::truncs.
+        int dropped = 0;
         auto copy_block = [&](int src) -> int {
             const int n = HS + hdr_of<S>(old, src)->nchild;
+            if (nfree + n > sc.keep_slots) { ++dropped; return -1; }
             const uint4* s4 = reinterpret_cast<const uint4*>(old + src);
             uint4* d4 = reinterpret_cast<uint4*>(nw + nfree);
             for (int i = lane; i < 2 * n; i += 64) d4[i] = s4[i];
@@ -420,13 +444,16 @@ __global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions
                     m &= m - 1;
                     const int src = __shfl(cb, b);
                     const int at = copy_block(src);
-                    if (lane == b) nw[scan + HS + i].block = at;
+                    if (lane == b) {
+                        nw[scan + HS + i].block = at;
+                        if (at < 0) nw[scan + HS + i].flags &= (uint8_t)~(F_OPEN | F_PSEUDO);
+                    }
                 }
             }
             scan += HS + nc;
             __syncthreads();
         }
-        if (lane == 0) nw[0] = child;
+        if (lane == 0) { nw[0] = child; c->truncs += dropped; }
     } else {
         // fresh root: it will be evaluated and expanded with raw priors (self_play.py:861-870).  The reference does
         // so even when the game just ended; that evaluation has no observable effect and is skipped here.
@@ -443,8 +470,56 @@ __global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions
         }
     }
     if (lane == 0) {
-        c->cur ^= 1; c->free_slot = nfree; c->finished = done ? 1 : 0; c->searching = 0; c->active = 0;
-        done_out[g] = done ? 1 : 0;
+        c->cur ^= 1; c->free_slot = nfree; c->finished = done ? 1 : 0; c->searching = 0; c->active = 0; c->moves = t + 1;
+        done_out[g] = done ? 1 : 0; moves_out[g] = t + 1;
+    }
+}
+
+// Finished games -> training positions, on the device (self_play.py:929-967 minus the 8-fold augmentation, which the replay
+// sampler applies on the fly): one workgroup per finished game scores its final position (getScoreAndTerritory, getWinner)
+// and writes, for each of its recorded moves, the bit-packed observation, the raw visit counts, z = +1 if the mover is the
+// winner else -1 (:931-934) and the territory seen from the mover (:938-940), at the game's offset of a position-major batch
+// -- exactly the arrays tg_replay_append stores.
+template <int S>
+__global__ __launch_bounds__(64) void k_harvest(EngineDev d, const int32_t* slot, const int32_t* off, uint32_t* o_obs,
+                                                int32_t* o_cnt, float* o_z, int8_t* o_own, uint8_t* o_pl, int32_t* o_winner,
+                                                float* o_score, int8_t* o_terr) {
+    using G = Geo<S>;
+    __shared__ WaveLds<S> lds;
+    __shared__ int8_t terr_s[G::PPAD];
+    const int f = blockIdx.x, lane = lane_id();
+    const int g = slot[f];
+    const size_t base = (size_t)off[f];
+    GameCtl* c = &d.ctl[g];
+    const int n = c->moves < d.hist_T ? c->moves : d.hist_T;
+    NodeRec* arena = arena_of<S>(d.arena, g, c->cur, d.sc.arena_slots);
+    BoardWave<S> bw; bw.init(&lds);
+    BoardState<S> st = hdr_of<S>(arena, arena[0].block)->st;
+    uint8_t owner[G::NW];
+    const float raw = tromp_taylor(bw, st, owner);
+    const float sc = raw - d.rules.komi;                               // go_env.cc:129
+    const int winner = sc > 0.f ? kBlack : kWhite;                     // environment.py:118-119
+#pragma unroll
+    for (int k = 0; k < G::NW; ++k) {
+        const int8_t tv = owner[k] == 1 ? 1 : owner[k] == 2 ? -1 : 0;  // go_env.cc:141-146
+        terr_s[bw.pt[k]] = tv;
+        if (o_terr && bw.pt[k] < G::P) o_terr[(size_t)f * G::P + bw.pt[k]] = tv;
+    }
+    if (lane == 0) { if (o_winner) o_winner[f] = winner; if (o_score) o_score[f] = sc; }
+    __syncthreads();
+    const uint32_t* h_obs = d.hist_obs + (size_t)g * d.hist_T * d.obs_words;
+    const int32_t* h_cnt = d.hist_cnt + (size_t)g * d.hist_T * G::A;
+    const uint8_t* h_pl = d.hist_pl + (size_t)g * d.hist_T;
+    for (int i = lane; i < n * d.obs_words; i += 64) o_obs[base * d.obs_words + i] = h_obs[i];
+    for (int i = lane; i < n * G::A; i += 64) o_cnt[base * G::A + i] = h_cnt[i];
+    for (int i = lane; i < n; i += 64) {
+        const int pl = h_pl[i];
+        o_z[base + i] = pl == winner ? 1.f : -1.f;
+        if (o_pl) o_pl[base + i] = (uint8_t)pl;
+    }
+    for (int i = lane; i < n * G::P; i += 64) {
+        const int tt = i / G::P, p = i - tt * G::P;
+        o_own[base * G::P + i] = h_pl[tt] == kBlack ? terr_s[p] : (int8_t)-terr_s[p];
     }
 }
 
@@ -494,6 +569,36 @@ int zero_counter(tg_ctx* ctx, int which) {
     return TG_OK;
 }
 
+// The per-game MT19937 streams live in HBM (tie-break draws happen inside k_collect) and are mirrored to pinned host memory
+// for the draws NumPy makes in float64 with libm (Dirichlet noise, the move's random_sample()).  Between the end of a search
+// and the next tg_sp_begin_move the host copy is the authoritative one, so a move costs one round trip, not one per draw site.
+int rng_to_host(tg_ctx* ctx) {
+    Engine* e = ctx->eng;
+    if (e->rng_on_host) return TG_OK;
+    TG_HIP(ctx, hipMemcpyAsync(e->h_rng, e->dev.rng, sizeof(tg_mt19937) * e->G, hipMemcpyDeviceToHost, ctx->stream));
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    e->rng_on_host = true;
+    return TG_OK;
+}
+int rng_to_device(tg_ctx* ctx) {
+    Engine* e = ctx->eng;
+    if (!e->rng_on_host) return TG_OK;
+    TG_HIP(ctx, hipMemcpyAsync(e->dev.rng, e->h_rng, sizeof(tg_mt19937) * e->G, hipMemcpyHostToDevice, ctx->stream));
+    e->rng_on_host = false;
+    return TG_OK;
+}
+
+// f(g) for g in [0, n) on a few host threads (independent games: per-game RNG streams, disjoint outputs)
+template <class F> void parallel_games(int n, F f) {
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = (int)(hw ? (hw > 16 ? 16 : hw) : 1);
+    if (n < 256 || nt <= 1) { for (int g = 0; g < n; ++g) f(g); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([=]() { for (int g = (int)((long long)n * t / nt), e2 = (int)((long long)n * (t + 1) / nt); g < e2; ++g) f(g); });
+    for (auto& x : th) x.join();
+}
+
 }  // namespace
 
 extern "C" {
@@ -514,6 +619,9 @@ int tg_engine_create(tg_ctx* ctx) {
     long long slots = cfg.arena_slots > 0 ? cfg.arena_slots : (3LL * cfg.num_simulation + 256) * (HS + A);
     if (slots < 4LL * (HS + A) || slots > 0x3fffffffLL) TG_FAIL(ctx, TG_ERR_ARG, "arena_slots out of range");
     sc.arena_slots = (int)slots;
+    // room a full search can need: one block per evaluated leaf, at most num_simulation + R of them per move
+    const long long headroom = ((long long)cfg.num_simulation + R + 1) * (HS + A);
+    sc.keep_slots = (int)(slots - headroom > 1 + HS + A ? slots - headroom : 1 + HS + A);
     e->dev.rules = ctx->rules;
     size_t arena_bytes = (size_t)G * 2 * (size_t)slots * sizeof(NodeRec);
     TG_HIP(ctx, hipMalloc((void**)&e->dev.arena, arena_bytes));
@@ -533,7 +641,19 @@ int tg_engine_create(tg_ctx* ctx) {
     TG_HIP(ctx, hipMalloc((void**)&e->d_i32, sizeof(int32_t) * (size_t)G * (A + 8)));
     TG_HIP(ctx, hipMalloc((void**)&e->d_f32, sizeof(float) * (size_t)G * (C * P + P + 8)));
     TG_HIP(ctx, hipMalloc((void**)&e->d_u8, (size_t)G * 4));
-    e->h_rng.resize(G);
+    TG_HIP(ctx, hipMalloc((void**)&e->d_fin, sizeof(int32_t) * 2 * (size_t)G));
+    TG_HIP(ctx, hipHostMalloc((void**)&e->h_rng, sizeof(tg_mt19937) * (size_t)G, hipHostMallocDefault));
+    memset(e->h_rng, 0, sizeof(tg_mt19937) * (size_t)G);
+    e->h_moves.assign(G, 0);
+    if (cfg.record_games) {
+        // a game has at most max_step moves (step_count starts at 1 and the game ends when it exceeds max_step, go_env.cc:67)
+        e->dev.hist_T = cfg.max_step > 0 ? cfg.max_step : 1;
+        e->dev.obs_words = (C * P + 31) / 32;
+        const size_t n = (size_t)G * e->dev.hist_T;
+        TG_HIP(ctx, hipMalloc((void**)&e->dev.hist_obs, sizeof(uint32_t) * n * e->dev.obs_words));
+        TG_HIP(ctx, hipMalloc((void**)&e->dev.hist_cnt, sizeof(int32_t) * n * A));
+        TG_HIP(ctx, hipMalloc((void**)&e->dev.hist_pl, n));
+    }
     e->h_noise.resize((size_t)G * A);
     e->h_nchild.resize(G);
     e->arena_bytes = arena_bytes;
@@ -545,8 +665,11 @@ void tg_engine_destroy(tg_ctx* ctx) {
     Engine* e = ctx->eng;
     if (!e) return;
     void* ptrs[] = {e->dev.arena, e->dev.ctl, e->dev.rng, e->dev.path_nodes, e->dev.path_len, e->dev.path_row, e->dev.row_game,
-                    e->dev.obs, e->dev.policy, e->dev.value, e->dev.counters, e->d_noise, e->d_i32, e->d_f32, e->d_u8};
+                    e->dev.obs, e->dev.policy, e->dev.value, e->dev.counters, e->d_noise, e->d_i32, e->d_f32, e->d_u8,
+                    e->d_fin, e->dev.hist_obs, e->dev.hist_cnt, e->dev.hist_pl};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (e->h_rng) (void)hipHostFree(e->h_rng);
+    e->hv_obs.release(); e->hv_cnt.release(); e->hv_z.release(); e->hv_own.release(); e->hv_pl.release(); e->hv_game.release();
     for (hipEvent_t ev : e->tev) (void)hipEventDestroy(ev);
     tg_net_destroy(ctx);
     delete e;
@@ -562,11 +685,12 @@ int tg_sp_reset(tg_ctx* ctx, const uint32_t* seeds, const uint8_t* mask) {
     const int G = e->G;
     if (e->batch_kind != BATCH_NONE) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_reset: an evaluation batch is pending");
     if (mask && !e->all_reset) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_reset: the first reset must cover every game (mask = NULL)");
-    // RNG streams are seeded on the host (np.random.seed(seed) per game) and shipped
-    TG_HIP(ctx, hipMemcpyAsync(e->h_rng.data(), e->dev.rng, sizeof(tg_mt19937) * G, hipMemcpyDeviceToHost, ctx->stream));
-    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int g = 0; g < G; ++g) if (!mask || mask[g]) tg_host_mt_seed(&e->h_rng[g], seeds[g]);
-    TG_HIP(ctx, hipMemcpyAsync(e->dev.rng, e->h_rng.data(), sizeof(tg_mt19937) * G, hipMemcpyHostToDevice, ctx->stream));
+    // RNG streams are seeded in the host mirror (np.random.seed(seed) per game); they travel with the next tg_sp_begin_move
+    if (mask) { int rc = rng_to_host(ctx); if (rc) return rc; }
+    else e->rng_on_host = true;                                       // every stream is overwritten: nothing to fetch
+    parallel_games(G, [&](int g) { if (!mask || mask[g]) tg_host_mt_seed(&e->h_rng[g], seeds[g]); });
+    for (int g = 0; g < G; ++g) if (!mask || mask[g]) e->h_moves[g] = 0;
+    e->fin_slot.clear(); e->fin_off.clear(); e->fin_positions = 0;   // unharvested records of restarted slots are gone
     uint8_t* d_mask = nullptr;
     if (mask) {
         TG_HIP(ctx, hipMemcpyAsync(e->d_u8, mask, G, hipMemcpyHostToDevice, ctx->stream));
@@ -594,6 +718,8 @@ int tg_sp_reset_from(tg_ctx* ctx, const void* states, const uint8_t* mask) {
     uint8_t* d_mask = nullptr;
     std::vector<uint8_t> all;
     if (mask) { TG_HIP(ctx, hipMemcpyAsync(e->d_u8, mask, G, hipMemcpyHostToDevice, ctx->stream)); d_mask = e->d_u8; }
+    for (int g = 0; g < G; ++g) if (!mask || mask[g]) e->h_moves[g] = 0;
+    e->fin_slot.clear(); e->fin_off.clear(); e->fin_positions = 0;
     zero_counter(ctx, CNT_ROWS);
     if (ctx->S == 9) hipLaunchKernelGGL(k_reset<9>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<9>*)ctx->env_in.p);
     else hipLaunchKernelGGL(k_reset<19>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<19>*)ctx->env_in.p);
@@ -684,14 +810,15 @@ int tg_sp_begin_move(tg_ctx* ctx, int selfplay, int num_simulation) {
         TG_LAUNCH(ctx, k_root_info, G, e->dev, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
                   d_nchild, (float*)nullptr);
         TG_HIP(ctx, hipMemcpyAsync(e->h_nchild.data(), d_nchild, sizeof(int32_t) * G, hipMemcpyDeviceToHost, ctx->stream));
-        TG_HIP(ctx, hipMemcpyAsync(e->h_rng.data(), e->dev.rng, sizeof(tg_mt19937) * G, hipMemcpyDeviceToHost, ctx->stream));
         TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (int g = 0; g < G; ++g)
+        { int rc = rng_to_host(ctx); if (rc) return rc; }
+        parallel_games(G, [&](int g) {
             if (e->h_nchild[g] > 0) tg_host_mt_dirichlet(&e->h_rng[g], 0.03, e->h_nchild[g], &e->h_noise[(size_t)g * A]);
-        TG_HIP(ctx, hipMemcpyAsync(e->dev.rng, e->h_rng.data(), sizeof(tg_mt19937) * G, hipMemcpyHostToDevice, ctx->stream));
+        });
         TG_HIP(ctx, hipMemcpyAsync(e->d_noise, e->h_noise.data(), sizeof(double) * (size_t)G * A, hipMemcpyHostToDevice, ctx->stream));
         TG_LAUNCH(ctx, k_noise, G, e->dev, (const double*)e->d_noise);
     }
+    { int rc = rng_to_device(ctx); if (rc) return rc; }
     TG_LAUNCH(ctx, k_begin, G, e->dev, num_simulation);
     TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return TG_OK;
@@ -701,6 +828,7 @@ int tg_sp_collect(tg_ctx* ctx, int32_t* n_active, int32_t* n_rows) {
     NEED_ENGINE(ctx);
     Engine* e = ctx->eng;
     if (e->batch_kind != BATCH_NONE) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_collect: an evaluation batch is pending");
+    { int rc = rng_to_device(ctx); if (rc) return rc; }
     TG_HIP(ctx, hipMemsetAsync(e->dev.counters, 0, sizeof(int32_t) * 2, ctx->stream));     // CNT_ROWS, CNT_ACTIVE
     const bool timed = e->tprof && e->tev_used + 4 <= e->tev.size();
     if (timed) { TG_HIP(ctx, hipEventRecord(e->tev[e->tev_used], ctx->stream)); }
@@ -713,7 +841,7 @@ int tg_sp_collect(tg_ctx* ctx, int32_t* n_active, int32_t* n_rows) {
     if (n_rows) *n_rows = cnt[CNT_ROWS];
     e->batch_kind = BATCH_LEAVES; e->batch_ready = cnt[CNT_ROWS] == 0;
     e->last_rows = cnt[CNT_ROWS];
-    if (cnt[CNT_ERRORS]) TG_FAIL(ctx, TG_ERR_ARENA, "tree arena / path overflow in at least one game (see tg_sp_game_errors)");
+    e->n_errors = cnt[CNT_ERRORS];          // games parked in error (tg_sp_game_errors); the others are unaffected
     return TG_OK;
 }
 
@@ -771,17 +899,15 @@ int tg_sp_draw_uniform(tg_ctx* ctx, double* u, const uint8_t* mask) {
     NEED_ENGINE(ctx);
     Engine* e = ctx->eng;
     const int G = e->G;
-    TG_HIP(ctx, hipMemcpyAsync(e->h_rng.data(), e->dev.rng, sizeof(tg_mt19937) * G, hipMemcpyDeviceToHost, ctx->stream));
-    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    { int rc = rng_to_host(ctx); if (rc) return rc; }
     for (int g = 0; g < G; ++g) u[g] = (!mask || mask[g]) ? tg_host_mt_random_sample(&e->h_rng[g]) : 0.0;
-    TG_HIP(ctx, hipMemcpyAsync(e->dev.rng, e->h_rng.data(), sizeof(tg_mt19937) * G, hipMemcpyHostToDevice, ctx->stream));
-    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return TG_OK;
 }
 
 int tg_sp_rng_state(tg_ctx* ctx, int game, tg_mt19937* out) {
     NEED_ENGINE(ctx);
     if (game < 0 || game >= ctx->eng->G || !out) return TG_ERR_ARG;
+    if (ctx->eng->rng_on_host) { *out = ctx->eng->h_rng[game]; return TG_OK; }
     TG_HIP(ctx, hipMemcpyAsync(out, ctx->eng->dev.rng + game, sizeof(tg_mt19937), hipMemcpyDeviceToHost, ctx->stream));
     TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return TG_OK;
@@ -796,13 +922,99 @@ int tg_sp_play(tg_ctx* ctx, const int32_t* actions, uint8_t* done) {
     int32_t* d_act = e->d_i32;
     TG_HIP(ctx, hipMemcpyAsync(d_act, actions, sizeof(int32_t) * G, hipMemcpyHostToDevice, ctx->stream));
     zero_counter(ctx, CNT_ROWS);
-    TG_LAUNCH(ctx, k_play, G, e->dev, (const int32_t*)d_act, e->d_u8);
+    int32_t* d_moves = e->d_i32 + G;
+    std::vector<int32_t> prev = e->h_moves;
+    TG_LAUNCH(ctx, k_play, G, e->dev, (const int32_t*)d_act, e->d_u8, d_moves);
     TG_HIP(ctx, hipMemcpyAsync(done, e->d_u8, G, hipMemcpyDeviceToHost, ctx->stream));
+    TG_HIP(ctx, hipMemcpyAsync(e->h_moves.data(), d_moves, sizeof(int32_t) * G, hipMemcpyDeviceToHost, ctx->stream));
     int32_t cnt[CNT_N];
     int rc = read_counters(ctx, cnt);
     if (rc) return rc;
     e->batch_kind = BATCH_ROOTS; e->batch_ready = cnt[CNT_ROWS] == 0; e->last_rows = cnt[CNT_ROWS];
-    if (cnt[CNT_ERRORS]) TG_FAIL(ctx, TG_ERR_ARENA, "tg_sp_play: action not among the root's children in at least one game");
+    e->n_errors = cnt[CNT_ERRORS];
+    // games this call finished (a slot that was already over does not move and is not listed again), ascending slot order
+    e->fin_slot.clear(); e->fin_off.clear(); e->fin_positions = 0;
+    for (int g = 0; g < G; ++g)
+        if (done[g] == 1 && e->h_moves[g] == prev[g] + 1) {
+            const int n = e->h_moves[g] < e->dev.hist_T ? e->h_moves[g] : e->dev.hist_T;
+            e->fin_slot.push_back(g); e->fin_off.push_back(e->fin_positions); e->fin_positions += n;
+        }
+    return TG_OK;
+}
+
+int tg_sp_finished(tg_ctx* ctx, int32_t* n_games, int32_t* n_positions) {
+    NEED_ENGINE(ctx);
+    if (n_games) *n_games = (int32_t)ctx->eng->fin_slot.size();
+    if (n_positions) *n_positions = ctx->eng->fin_positions;
+    return TG_OK;
+}
+
+int tg_sp_harvest(tg_ctx* ctx, uint32_t* obs_bits, int32_t* counts, float* z, int8_t* own, uint8_t* player, int device_out,
+                  int32_t* slot, int32_t* n_moves, int32_t* winner, float* score, int8_t* terr) {
+    NEED_ENGINE(ctx);
+    Engine* e = ctx->eng;
+    if (!e->dev.hist_obs) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_harvest: the context was created with record_games = 0");
+    const int nf = (int)e->fin_slot.size(), np = e->fin_positions, P = ctx->P, A = ctx->A, W = e->dev.obs_words;
+    if (nf == 0) return TG_OK;
+    if (!obs_bits || !counts || !z || !own) return TG_ERR_ARG;
+    TG_HIP(ctx, hipMemcpyAsync(e->d_fin, e->fin_slot.data(), sizeof(int32_t) * nf, hipMemcpyHostToDevice, ctx->stream));
+    TG_HIP(ctx, hipMemcpyAsync(e->d_fin + e->G, e->fin_off.data(), sizeof(int32_t) * nf, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t* d_obs = obs_bits; int32_t* d_cnt = counts; float* d_z = z; int8_t* d_own = own; uint8_t* d_pl = player;
+    if (!device_out) {
+        if (e->hv_obs.reserve(sizeof(uint32_t) * (size_t)np * W) || e->hv_cnt.reserve(sizeof(int32_t) * (size_t)np * A) ||
+            e->hv_z.reserve(sizeof(float) * (size_t)np) || e->hv_own.reserve((size_t)np * P) || e->hv_pl.reserve((size_t)np))
+            TG_FAIL(ctx, TG_ERR_HIP, "hipMalloc failed");
+        d_obs = (uint32_t*)e->hv_obs.p; d_cnt = (int32_t*)e->hv_cnt.p; d_z = (float*)e->hv_z.p; d_own = (int8_t*)e->hv_own.p;
+        d_pl = player ? (uint8_t*)e->hv_pl.p : nullptr;
+    }
+    // per-game results: winner i32[nf] | score f32[nf] | terr i8[nf][P]
+    if (e->hv_game.reserve((size_t)nf * (8 + P))) TG_FAIL(ctx, TG_ERR_HIP, "hipMalloc failed");
+    int32_t* d_w = (int32_t*)e->hv_game.p; float* d_s = (float*)(d_w + nf); int8_t* d_t = (int8_t*)(d_s + nf);
+    TG_LAUNCH(ctx, k_harvest, nf, e->dev, (const int32_t*)e->d_fin, (const int32_t*)(e->d_fin + e->G), d_obs, d_cnt, d_z, d_own,
+              d_pl, d_w, d_s, d_t);
+    if (!device_out) {
+        TG_HIP(ctx, hipMemcpyAsync(obs_bits, d_obs, sizeof(uint32_t) * (size_t)np * W, hipMemcpyDeviceToHost, ctx->stream));
+        TG_HIP(ctx, hipMemcpyAsync(counts, d_cnt, sizeof(int32_t) * (size_t)np * A, hipMemcpyDeviceToHost, ctx->stream));
+        TG_HIP(ctx, hipMemcpyAsync(z, d_z, sizeof(float) * (size_t)np, hipMemcpyDeviceToHost, ctx->stream));
+        TG_HIP(ctx, hipMemcpyAsync(own, d_own, (size_t)np * P, hipMemcpyDeviceToHost, ctx->stream));
+        if (player) TG_HIP(ctx, hipMemcpyAsync(player, d_pl, (size_t)np, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (winner) TG_HIP(ctx, hipMemcpyAsync(winner, d_w, sizeof(int32_t) * nf, hipMemcpyDeviceToHost, ctx->stream));
+    if (score) TG_HIP(ctx, hipMemcpyAsync(score, d_s, sizeof(float) * nf, hipMemcpyDeviceToHost, ctx->stream));
+    if (terr) TG_HIP(ctx, hipMemcpyAsync(terr, d_t, (size_t)nf * P, hipMemcpyDeviceToHost, ctx->stream));
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));                    // device outputs are complete on return as well
+    for (int i = 0; i < nf; ++i) {
+        if (slot) slot[i] = e->fin_slot[i];
+        if (n_moves) n_moves[i] = (i + 1 < nf ? e->fin_off[i + 1] : np) - e->fin_off[i];
+    }
+    return TG_OK;
+}
+
+int tg_sp_game_errors(tg_ctx* ctx, int32_t* n_errors, int32_t* err) {
+    NEED_ENGINE(ctx);
+    Engine* e = ctx->eng;
+    if (n_errors) *n_errors = e->n_errors;
+    if (err) {
+        std::vector<GameCtl> h(e->G);
+        TG_HIP(ctx, hipMemcpyAsync(h.data(), e->dev.ctl, sizeof(GameCtl) * e->G, hipMemcpyDeviceToHost, ctx->stream));
+        TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        int n = 0;
+        for (int g = 0; g < e->G; ++g) { err[g] = h[g].error; n += h[g].error != 0; }
+        e->n_errors = n;
+        if (n_errors) *n_errors = n;
+    }
+    return TG_OK;
+}
+
+int tg_sp_tree_truncations(tg_ctx* ctx, uint64_t* blocks) {
+    NEED_ENGINE(ctx);
+    Engine* e = ctx->eng;
+    std::vector<GameCtl> h(e->G);
+    TG_HIP(ctx, hipMemcpyAsync(h.data(), e->dev.ctl, sizeof(GameCtl) * e->G, hipMemcpyDeviceToHost, ctx->stream));
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t n = 0;
+    for (const GameCtl& c : h) n += c.truncs;
+    if (blocks) *blocks = n;
     return TG_OK;
 }
 

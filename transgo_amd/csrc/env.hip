@@ -96,6 +96,7 @@ void tg_config_default(tg_config* c) {
     c->n_games = 0; c->num_simulation = 210; c->parallel_readouts = 4; c->wu_loss = 2;  // configure.py:29-33
     c->c_puct1 = 3; c->c_puct2 = 0.05;                                                 // configure.py:26-27
     c->net_blocks = 6; c->net_filters = 128; c->device = 0;
+    c->record_games = 1;
 }
 
 const char* tg_last_error(const tg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }

@@ -109,7 +109,8 @@ void tg_replay_destroy(tg_replay* h) {
 // Append n un-augmented positions (ring buffer over positions = the reference's ring over 8-tuples, replay_buffer.py:30-34):
 // obs_bits u32[n][obs_words] (bit i = plane-major flat index i of env.encode), counts i32[n][A] raw root visit counts,
 // z f32[n] (+1/-1, self_play.py:931-934), own i8[n][P] (territory from the mover's side, self_play.py:938-940).
-int tg_replay_append(tg_replay* h, const uint32_t* obs_bits, const int32_t* counts, const float* z, const int8_t* own, int n) {
+static int replay_append(tg_replay* h, const uint32_t* obs_bits, const int32_t* counts, const float* z, const int8_t* own, int n,
+                         hipMemcpyKind kind) {
     if (!h || !obs_bits || !counts || !z || !own || n < 0) return TG_ERR_ARG;
     tg_ctx* ctx = h->ctx; Replay& r = h->r;
     TG_HIP(ctx, hipSetDevice(ctx->cfg.device));
@@ -118,15 +119,25 @@ int tg_replay_append(tg_replay* h, const uint32_t* obs_bits, const int32_t* coun
         const int at = (int)(r.appended % r.cap);
         const int k = (n - done) < (r.cap - at) ? (n - done) : (r.cap - at);
         TG_HIP(ctx, hipMemcpyAsync(r.obs + (size_t)at * r.obs_words, obs_bits + (size_t)done * r.obs_words,
-                                   sizeof(uint32_t) * (size_t)k * r.obs_words, hipMemcpyHostToDevice, ctx->stream));
+                                   sizeof(uint32_t) * (size_t)k * r.obs_words, kind, ctx->stream));
         TG_HIP(ctx, hipMemcpyAsync(r.counts + (size_t)at * r.A, counts + (size_t)done * r.A, sizeof(int32_t) * (size_t)k * r.A,
-                                   hipMemcpyHostToDevice, ctx->stream));
-        TG_HIP(ctx, hipMemcpyAsync(r.z + at, z + done, sizeof(float) * k, hipMemcpyHostToDevice, ctx->stream));
-        TG_HIP(ctx, hipMemcpyAsync(r.own + (size_t)at * r.P, own + (size_t)done * r.P, (size_t)k * r.P, hipMemcpyHostToDevice, ctx->stream));
+                                   kind, ctx->stream));
+        TG_HIP(ctx, hipMemcpyAsync(r.z + at, z + done, sizeof(float) * k, kind, ctx->stream));
+        TG_HIP(ctx, hipMemcpyAsync(r.own + (size_t)at * r.P, own + (size_t)done * r.P, (size_t)k * r.P, kind, ctx->stream));
         r.appended += k; done += k;
     }
     TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return TG_OK;
+}
+
+int tg_replay_append(tg_replay* h, const uint32_t* obs_bits, const int32_t* counts, const float* z, const int8_t* own, int n) {
+    return replay_append(h, obs_bits, counts, z, own, n, hipMemcpyHostToDevice);
+}
+// The same with the four arrays already in this GPU's memory (what tg_sp_harvest(device_out = 1) or an RCCL gather delivers):
+// finished games go from the search engine into the store without touching the host.  The arrays must be complete (their
+// producer synchronised) when this is called.
+int tg_replay_append_dev(tg_replay* h, const uint32_t* obs_bits, const int32_t* counts, const float* z, const int8_t* own, int n) {
+    return replay_append(h, obs_bits, counts, z, own, n, hipMemcpyDeviceToDevice);
 }
 
 // Number of reference-buffer entries currently addressable (8 per stored position) and the ring position, as info() does

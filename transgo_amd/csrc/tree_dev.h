@@ -51,13 +51,14 @@ struct GameCtl {
     int32_t finished;     // root state is terminal
     int32_t error;        // sticky: 1 arena overflow, 2 depth overflow, 4 bad action
     int32_t searching;    // begin_move issued
-    int32_t pad0[2];
+    int32_t moves;        // moves played in this game = entries of its device-side record (self_play.py:917-926)
+    int32_t pad0;
     unsigned long long sims;        // completed backups (terminal ones included)
     unsigned long long evals;       // leaves sent to the evaluator
     unsigned long long depth_sum;   // sum of selection depths
     unsigned long long tie_draws;   // RNG words consumed by tie breaks
     unsigned long long child_sum;   // children scored by PUCT, summed over selection levels (mean fan-out = child_sum / depth_sum)
-    unsigned long long pad1;
+    unsigned long long truncs;      // sub-tree blocks dropped at re-rooting because the kept tree outgrew the arena (k_play)
 };
 
 struct SearchCfg {
@@ -66,6 +67,7 @@ struct SearchCfg {
     double c1, c2;      // c_puct1, c_puct2
     float c1f, c2f;     // their float32 roundings (weak Python scalars next to float32 operands)
     int arena_slots;    // per half
+    int keep_slots;     // most slots a re-rooted tree may keep (arena_slots minus the room of one full search)
     int maxd;           // path capacity
     int A;
 };

@@ -73,7 +73,9 @@ class SelfPlayEngine:
         self.G, self.S, self.P, self.A, self.C = n_games, board_size, board_size ** 2, board_size ** 2 + 1, encode_dim
         self.num_simulation = num_simulation
         self.evaluator = evaluator            # None -> network on the GPU; callable(obs)->(policy, value) -> injected
-        self.finished = np.zeros(n_games, bool)
+        self.finished = np.zeros(n_games, bool)      # slots that take no part in the next search (game over, parked, in error)
+        self.errored = np.zeros(n_games, bool)       # slots parked by a tree-arena overflow (restart them with reset(mask))
+        self.device = device
 
     def close(self):
         self.ctx.close()
@@ -105,9 +107,9 @@ class SelfPlayEngine:
         self._evaluate()
         self.ctx.call("tg_sp_expand_roots")
         if mask is None:
-            self.finished[:] = False
+            self.finished[:] = False; self.errored[:] = False
         else:
-            self.finished[np.asarray(mask, bool)] = False
+            self.finished[np.asarray(mask, bool)] = False; self.errored[np.asarray(mask, bool)] = False
 
     def reset_from(self, states, mask=None):
         """Fresh roots at given positions: the first half of select_action (self_play.py:689-700).  states: [G, state_size]
@@ -158,6 +160,12 @@ class SelfPlayEngine:
         self.ctx.call("tg_sp_root_info", _ptr(vis), _ptr(rn), _ptr(pl), _ptr(st), _ptr(ob))
         return vis, rn, pl, st, ob
 
+    def root_visits(self):
+        """Visit counts and ply counters only (what move selection needs): 4*(A+1) bytes per game across PCIe."""
+        vis = np.zeros((self.G, self.A), np.int32); st = np.zeros(self.G, np.int32)
+        self.ctx.call("tg_sp_root_info", _ptr(vis), None, None, _ptr(st), None)
+        return vis, st
+
     def choose_moves(self, visits, steps, selfplay=True):
         """self_play.py:666-683 for every live game, in NumPy float64 with the reference's own operations:
         counts==1 -> 0, pi = counts/sum, p ~ counts**(1/tau), and np.random.choice(A, p) spelt out as NumPy implements it
@@ -171,13 +179,47 @@ class SelfPlayEngine:
         return choose_moves_batch(visits, steps, u, live, selfplay)
 
     def play(self, actions):
-        """update_with_action (self_play.py:857-872)."""
+        """update_with_action (self_play.py:857-872); the move's record entry is written on the device first.  Returns the
+        mask of games that are over; `self.errored` marks slots parked by an arena overflow (neither over nor playable)."""
         done = np.zeros(self.G, np.uint8)
         self.ctx.call("tg_sp_play", _ptr(np.ascontiguousarray(actions, np.int32)), _ptr(done))
         self._evaluate()
         self.ctx.call("tg_sp_expand_roots")
-        self.finished = done.astype(bool)
-        return self.finished.copy()
+        self.finished = done != 0
+        self.errored = done == 2
+        return done == 1
+
+    def game_errors(self):
+        n = ctypes.c_int32(); err = np.zeros(self.G, np.int32)
+        self.ctx.call("tg_sp_game_errors", ctypes.byref(n), _ptr(err))
+        return err
+
+    def harvest(self, device=False, seeds=None):
+        """The games the last play() finished, as one position-major batch (transgo_amd.records.Harvest), or None.
+        device=True: the batch is a torch uint8 tensor in this GPU's memory and only the per-game tables cross PCIe."""
+        from . import records
+        ng, npos = ctypes.c_int32(), ctypes.c_int32()
+        self.ctx.call("tg_sp_finished", ctypes.byref(ng), ctypes.byref(npos))
+        ng, npos = ng.value, npos.value
+        if ng == 0:
+            return None
+        sec, total = records.layout(self.S, self.C, ng, npos)
+        hdr = records.header_bytes(self.S, self.C, ng)
+        if device:
+            import torch
+            buf = torch.empty(total, dtype=torch.uint8, device=torch.device("cuda", self.device))
+            host = records.Harvest(self.S, self.C, ng, 0, np.zeros(hdr, np.uint8))        # per-game tables are written on the host
+        else:
+            buf = np.zeros(total, np.uint8)
+        h = records.Harvest(self.S, self.C, ng, npos, buf)
+        t = host if device else h
+        self.ctx.call("tg_sp_harvest", h.ptr("obs_bits"), h.ptr("counts"), h.ptr("z"), h.ptr("own"), h.ptr("player"),
+                      1 if device else 0, t.ptr("slot"), t.ptr("n_moves"), t.ptr("winner"), t.ptr("score"), t.ptr("terr"))
+        if seeds is not None:
+            t.view("seed")[:] = np.asarray(seeds, np.uint32)[t.view("slot")]
+        if device:
+            buf[:hdr].copy_(torch.from_numpy(host.buf))
+        return h
 
     def final(self):
         score = np.zeros(self.G, np.float32); terr = np.zeros((self.G, self.P), np.float32); win = np.zeros(self.G, np.int32)
@@ -192,5 +234,7 @@ class SelfPlayEngine:
     def stats(self):
         v = [ctypes.c_uint64() for _ in range(4)]; e = ctypes.c_int32(); m = ctypes.c_int32()
         self.ctx.call("tg_sp_stats", *[ctypes.byref(x) for x in v], ctypes.byref(e), ctypes.byref(m))
+        tr = ctypes.c_uint64()
+        self.ctx.call("tg_sp_tree_truncations", ctypes.byref(tr))
         return dict(sims=v[0].value, evals=v[1].value, depth_sum=v[2].value, tie_draws=v[3].value, errors=e.value,
-                    max_slots=m.value)
+                    max_slots=m.value, truncated_blocks=tr.value)

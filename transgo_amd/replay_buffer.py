@@ -12,13 +12,21 @@ class ReplayMemory_Random:
         self.index = 0
         self.last_save_index = 0
         self.load_index = 0
-        self.data = np.empty(self.capacity, dtype=object)          # replay_buffer.py:25-27 (blank tuples on demand)
-        self._blank = (np.zeros((config.encode_state_channels, config.board_size, config.board_size)),
-                       np.zeros((config.board_size ** 2 + 1)), 0.0, np.zeros((config.board_size ** 2)))
-        self.data[:] = [self._blank] * self.capacity if self.capacity <= 4096 else None
+        # replay_buffer.py:21-27: np.array([blank]*capacity, dtype=object) is a 2-D object array of shape (capacity, 4) -- one
+        # column per tuple field, every row referring to the same four blank objects.  Built here by broadcasting one row
+        # (the same result without a capacity-long Python list), so save()/load() dicts are interchangeable with the
+        # reference's.
+        blank = (np.zeros((config.encode_state_channels, config.board_size, config.board_size)),
+                 np.zeros((config.board_size ** 2 + 1)), 0.0, np.zeros((config.board_size ** 2)))
+        row = np.empty(4, dtype=object)
+        for i, v in enumerate(blank):
+            row[i] = v
+        self.data = np.empty((self.capacity, 4), dtype=object)
+        self.data[:] = row
 
     def append(self, observation, act_prob, win_z, own_z):          # replay_buffer.py:30-34
-        self.data[self.index] = (observation, act_prob, win_z, own_z)
+        row = self.data[self.index]                                 # assigning a tuple would broadcast the arrays' elements
+        row[0], row[1], row[2], row[3] = observation, act_prob, win_z, own_z
         self.index = (self.index + 1) % self.capacity
         self.full = self.full or self.index == 0
 
@@ -107,6 +115,15 @@ class DeviceReplayMemory:
         self._lib.check(self.ctx.lib, self.ctx.h, self.ctx.lib.tg_replay_append(self.h, p(np.ascontiguousarray(packed)), p(counts), p(z),
                                                                                 p(np.ascontiguousarray(own)), n))
 
+    def append_harvest(self, h):
+        """Finished games as a records.Harvest batch: straight from HBM when the batch lives on this GPU (tg_sp_harvest or an
+        RCCL gather wrote it there), from host arrays otherwise."""
+        fn = self.ctx.lib.tg_replay_append_dev if h.on_device else self.ctx.lib.tg_replay_append
+        if not h.on_device:
+            h = h.to_host()
+        self._lib.check(self.ctx.lib, self.ctx.h, fn(self.h, h.ptr("obs_bits"), h.ptr("counts"), h.ptr("z"), h.ptr("own"),
+                                                     h.n_positions))
+
     def info(self):                                                  # replay_buffer.py:89-94, in units of reference entries
         e, i, f = self._ct.c_longlong(), self._ct.c_longlong(), self._ct.c_int()
         self.ctx.lib.tg_replay_info(self.h, self._ct.byref(e), self._ct.byref(i), self._ct.byref(f))
@@ -131,42 +148,50 @@ class DeviceReplayMemory:
 
 
 # ---- packed on-disk / wire format (replaces the pickled object arrays of replay_buffer.py:49-87) -----------
-# One file = a sequence of finished games in the exact, compact form that also travels between GPUs
-# (transgo_amd.distributed.pack_records): bit-packed planes (10*S*S bits), raw visit counts, side to move, and per game the
-# winner and territory.  ~0.43 KB per position instead of ~36 KB for its 8 pickled float tuples; pi / z / own and the 8
-# symmetries are regenerated bit-identically by the loader.
-_MAGIC = b"TGRP1\0"
+# One file = one batch of finished games in the exact, compact form that also travels between GPUs and that tg_sp_harvest
+# writes (transgo_amd.records): bit-packed planes (10*S*S bits), raw visit counts, z, territory from the mover's side, side
+# to move, and per game the winner / territory / seed.  ~0.52 KB per position instead of ~36 KB for its 8 pickled float
+# tuples; pi and the 8 symmetries are regenerated bit-identically by the loader.
+_MAGIC = b"TGRP2\0"
 
 
-def save_packed(path, records, board_size, encode_dim):
-    from .distributed import pack_records
-    payload = pack_records(records, board_size, encode_dim)
+def save_packed(path, games, board_size, encode_dim):
+    """games: a records.Harvest or a list of GameRecord."""
+    from . import records
+    h = games if isinstance(games, records.Harvest) else records.from_records(games, board_size, encode_dim)
+    h = h.to_host()
     with open(path, "wb") as f:
         f.write(_MAGIC)
-        f.write(np.array([board_size, encode_dim, len(records)], np.int32).tobytes())
-        f.write(payload.tobytes())
+        f.write(np.array([board_size, encode_dim, h.n_games, h.n_positions], np.int32).tobytes())
+        f.write(h.buf.tobytes())
+
+
+def load_packed_batch(path):
+    """-> records.Harvest (host)."""
+    from . import records
+    with open(path, "rb") as f:
+        if f.read(len(_MAGIC)) != _MAGIC:
+            raise ValueError("not a packed replay file")
+        S, C, g, n = (int(x) for x in np.frombuffer(f.read(16), np.int32))
+        buf = np.frombuffer(f.read(), np.uint8).copy()
+    if len(buf) != records.layout(S, C, g, n)[1]:
+        raise ValueError("truncated packed replay file")
+    return records.Harvest(S, C, g, n, buf)
 
 
 def load_packed(path):
     """-> list of GameRecord (observations, visits, pis, players, winner, territory)."""
-    from .distributed import unpack_records
-    with open(path, "rb") as f:
-        if f.read(len(_MAGIC)) != _MAGIC:
-            raise ValueError("not a packed replay file")
-        S, C, n = np.frombuffer(f.read(12), np.int32)
-        recs = unpack_records(np.frombuffer(f.read(), np.uint8), int(S), int(C))
-    if len(recs) != n:
-        raise ValueError("truncated packed replay file")
-    return recs
+    return load_packed_batch(path).records()
 
 
 def load_packed_into(path, mem):
     """Feed a packed file into any buffer with the reference's append(obs, pi, z, own) (replay_buffer.py:30-34), in the
-    reference's order.  Returns the number of tuples appended."""
-    from .self_play import game_targets
+    reference's order (or into a DeviceReplayMemory as one batch).  Returns the number of reference tuples that makes."""
+    h = load_packed_batch(path)
+    if hasattr(mem, "append_harvest"):
+        mem.append_harvest(h)
+        return 8 * h.n_positions
     k = 0
-    for r in load_packed(path):
-        S = int(round(len(r.territory) ** 0.5))
-        for t in game_targets(r.observations, r.pis, r.players, r.winner, r.territory, S):
-            mem.append(*t); k += 1
+    for t in h.targets():
+        mem.append(*t); k += 1
     return k

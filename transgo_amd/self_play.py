@@ -63,8 +63,20 @@ class GameRecord:
         self.winner, self.territory, self.score, self.seed = None, None, None, seed
 
 
+def default_seed(rank, world, n_games, g, k):
+    """Seed of the k-th game played in slot g of rank `rank`: distinct for every (rank, slot, restart) by construction --
+    consecutive blocks of n_games seeds per (restart, rank) -- so no two games of a job share an RNG stream.  First games of
+    rank 0 get s_g = g."""
+    s = (k * max(1, world) + rank) * n_games + g
+    if s >= 2 ** 32:
+        raise OverflowError("game seed space exhausted (2**32 games)")
+    return s
+
+
 class BatchedSelfPlay:
-    """G concurrent self-play games in lock step (one engine, one GPU)."""
+    """G concurrent self-play games in lock step (one engine, one GPU).  The per-game material the reference keeps in Python
+    lists (observations, visit counts, players; self_play.py:917-926) lives in HBM inside the engine; a finished game leaves
+    it as a `records.Harvest` batch -- in device memory when the consumer is on the GPU too."""
 
     def __init__(self, config, n_games, device=0, rank=0, world=1, evaluator=None, keep_obs=True, arena_slots=0,
                  seed_fn=None):
@@ -82,23 +94,27 @@ class BatchedSelfPlay:
             encode_dim=config.encode_state_channels, net_blocks=self.blocks, net_filters=self.filters,
             arena_slots=arena_slots, device=device, evaluator=evaluator,
             net_precision=getattr(config, "inference_dtype", "f32"))
-        self.keep_obs = keep_obs
         self.seed_fn = seed_fn
         self.games_started = np.zeros(n_games, np.int64)
-        self.records = [None] * n_games
+        self.seeds = np.zeros(n_games, np.uint32)          # seed of the game now running in each slot
         self.moves_played = 0
         self.games_finished = 0
+        self.games_dropped = 0                             # games abandoned because their tree outgrew the arena
         self._started = False
-        self._hist, self._hist_base, self._move_idx = [], 0, 0
-        self._game_start = np.zeros(n_games, np.int64)
 
     def seed_of(self, g):
-        """Game seeds s = 1000*rank + g for the first game of a slot, then a fixed stride per restart."""
+        k = int(self.games_started[g])
         if self.seed_fn is not None:
-            return int(self.seed_fn(g, int(self.games_started[g]))) % (2 ** 32)
-        return (1000 * self.rank + g + 1000003 * int(self.games_started[g]) * max(1, self.world)) % (2 ** 32)
+            return int(self.seed_fn(g, k)) % (2 ** 32)
+        return default_seed(self.rank, self.world, self.G, g, k)
 
     def set_weights(self, state_dict):
+        """state_dict of the configured layout; a MainNetwork state_dict (the reference trainer's, model.py:49-76) switches a
+        default-configured worker to that architecture instead of failing on the key names."""
+        if "main_network.res_conv2.conv_1.weight" in state_dict and self.arch.code != _model.transgo_arch().code:
+            self.arch = _model.transgo_arch()
+        elif "main_network.res_blocks.0.conv_1.weight" in state_dict and self.arch.policy_attention:
+            self.arch = _model.tower_arch(self.blocks)
         _model.load_into(self.engine.ctx, state_dict, self.S, self.config.encode_state_channels, self.filters, arch=self.arch)
 
     def set_weights_blob(self, blob):
@@ -108,96 +124,125 @@ class BatchedSelfPlay:
 
     def _reset(self, mask=None):
         idx = range(self.G) if mask is None else np.flatnonzero(mask)
-        seeds = np.zeros(self.G, np.uint32)
         for g in idx:
-            seeds[g] = self.seed_of(g)
-            self.records[g] = GameRecord(int(seeds[g]))
+            self.seeds[g] = self.seed_of(g)
             self.games_started[g] += 1
-        self.engine.reset(seeds, mask)
+        self.engine.reset(self.seeds, mask)
 
     def start(self):
         self._reset(None)
         self._started = True
 
-    def step(self, selfplay=True):
-        """One move of every game: get_action_probs + update_with_action (self_play.py:917-926).  Returns the records
-        of the games that ended with this move; their slots are restarted.  Per-move material is kept as whole-batch
-        arrays (observations bit-packed) and only sliced per game when a game ends."""
+    def advance(self, selfplay=True, device=False, num_simulation=0):
+        """One move of every game: get_action_probs + update_with_action (self_play.py:917-926).  Returns the games this
+        move finished as a `records.Harvest` (None if none did); their slots are restarted with fresh seeds, and so are slots
+        whose tree outgrew its arena (counted in games_dropped)."""
         if not self._started:
             self.start()
         eng = self.engine
-        eng.search(selfplay)
-        vis, rn, players, steps, obs = eng.root_info(obs=self.keep_obs)
-        actions, pis = eng.choose_moves(vis, steps, selfplay)
-        packed = np.packbits(obs.reshape(self.G, -1).astype(np.uint8), axis=1) if self.keep_obs else None
-        self._hist.append((packed, vis, players.astype(np.int8)))
+        live = int((~eng.finished).sum())
+        eng.search(selfplay, num_simulation)
+        vis, steps = eng.root_visits()
+        actions, _ = eng.choose_moves(vis, steps, selfplay)
         done = eng.play(actions)
-        self.moves_played += self.G
-        finished = []
+        self.moves_played += live
+        h = None
         if done.any():
-            score, terr, win = eng.final()
-            C, S = self.config.encode_state_channels, self.S
-            for g in np.flatnonzero(done):
-                r = self.records[g]
-                first = int(self._game_start[g]) - self._hist_base
-                for pk, vi, pl in self._hist[first:]:
-                    if pk is not None:
-                        r.observations.append(np.unpackbits(pk[g])[:C * S * S].reshape(C, S, S).astype(np.float32))
-                    counts = np.array([int(c) for c in vi[g]])
-                    counts = np.where(counts == 1, 0, counts)                  # self_play.py:666-671
-                    r.visits.append(vi[g].copy()); r.pis.append(counts / np.sum(counts)); r.players.append(int(pl[g]))
-                r.winner, r.territory, r.score = int(win[g]), terr[g].copy(), float(score[g])
-                finished.append(r)
-            self.games_finished += len(finished)
-            self._reset(done)
-        self._move_idx += 1
-        self._game_start[done] = self._move_idx
-        drop = int(self._game_start.min()) - self._hist_base        # history older than every live game
-        if drop > 0:
-            del self._hist[:drop]
-            self._hist_base += drop
-        return finished
+            h = eng.harvest(device=device, seeds=self.seeds)
+            self.games_finished += h.n_games
+        restart = done | eng.errored
+        if restart.any():
+            self.games_dropped += int(eng.errored.sum())
+            self._reset(restart)
+        return h
+
+    def step(self, selfplay=True):
+        """advance() with the finished games unpacked into GameRecord objects (host lists, as the reference keeps them)."""
+        h = self.advance(selfplay)
+        return h.records() if h is not None else []
 
     def targets(self, record):
         return game_targets(record.observations, record.pis, record.players, record.winner, record.territory, self.S)
 
 
-class SelfPlay:
-    """Reference actor surface (self_play.py:881-983)."""
+def _bump(storage, key, n):
+    """n times the increment form set_info(key) (shared_storage.py:27-28 plus its schedules), as ONE call when the storage
+    object offers add_info (transgo_amd.shared_storage does; the result is identical), else n calls."""
+    if n <= 0:
+        return
+    if hasattr(storage, "add_info"):
+        _call(storage.add_info, key, int(n))
+    else:
+        for _ in range(int(n)):
+            _call(storage.set_info, key)
 
-    def __init__(self, config, n_games=None, device=0, rank=0, world=1):
+
+class SelfPlay:
+    """Reference actor surface (self_play.py:881-983).  With torch.distributed initialised every rank runs one of these over
+    its own shard of the games; rank 0 is the one that talks to the storage / replay actors (the others pass None)."""
+
+    def __init__(self, config, n_games=None, device=0, rank=0, world=1, evaluator=None):
         self.config = config
         self.n_games = n_games or getattr(config, "concurrent_games", 1024)
-        self.worker = BatchedSelfPlay(config, self.n_games, device=device, rank=rank, world=world)
-        self._weights_version = None
+        self.worker = BatchedSelfPlay(config, self.n_games, device=device, rank=rank, world=world, evaluator=evaluator)
+        self._train_steps_seen = None      # storage's now_train_steps when the weights were last fetched
+        self._blob_digest = None           # content digest of the packed weights now on the GPU
+
+    @staticmethod
+    def _dist():
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        return dist, multi, (dist.get_rank() if multi else 0), (dist.get_world_size() if multi else 1)
+
+    def _fetch_blob(self, shared_storage_worker):
+        """Rank-0 side of the weight refresh (self_play.py:913): ask the storage for its train-step counter first and fetch
+        + pack the weights only when it moved (the trainer publishes weights inside train steps only, trainer.py:74-89, so
+        the counter is a monotonic version); what then decides an upload is the content digest of the packed blob.  A storage
+        without that counter is asked for its weights every time.  Returns the new blob or None."""
+        import hashlib
+        wk = self.worker
+        try:
+            steps = _get(_call(shared_storage_worker.get_info, "now_train_steps"))
+        except KeyError:
+            steps = None
+        if steps is not None and steps == self._train_steps_seen and self._blob_digest is not None:
+            return None
+        self._train_steps_seen = steps
+        w = _get(_call(shared_storage_worker.get_info, "weights"))
+        if w is None:
+            return None
+        if "main_network.res_conv2.conv_1.weight" in w and not wk.arch.policy_attention:
+            wk.arch = _model.transgo_arch()
+        blob = _model.pack_weights(w, wk.S, wk.config.encode_state_channels, wk.filters, arch=wk.arch)
+        digest = hashlib.blake2b(blob.tobytes(), digest_size=16).digest()
+        if digest == self._blob_digest:
+            return None
+        self._blob_digest = digest
+        return blob
 
     def _refresh_weights(self, shared_storage_worker):
         """self_play.py:913.  With several ranks, rank 0 asks the storage actor and every other rank receives the packed
-        blob by one RCCL broadcast (transgo_amd.distributed.broadcast_weights)."""
-        import torch.distributed as dist
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        w = None
-        if not multi or dist.get_rank() == 0:
-            w = _get(_call(shared_storage_worker.get_info, "weights"))
+        blob by one RCCL broadcast (transgo_amd.distributed.broadcast_weights), only when the content changed."""
+        dist, multi, rank, _ = self._dist()
+        wk = self.worker
+        blob = self._fetch_blob(shared_storage_worker) if rank == 0 else None
         if not multi:
-            if w is not None and id(w) != self._weights_version:
-                self.worker.set_weights(w)
-                self._weights_version = id(w)
+            if blob is not None:
+                wk.set_weights_blob(blob)
             return
         import torch
         from .distributed import broadcast_weights
-        wk = self.worker
         dev = torch.device("cuda", wk.device) if dist.get_backend() == "nccl" else torch.device("cpu")
-        changed = torch.tensor([int(w is not None and id(w) != self._weights_version)], device=dev)
-        dist.broadcast(changed, src=0)
-        if not int(changed.item()):
+        flag = torch.tensor([0 if blob is None else (2 if wk.arch.policy_attention else 1)], device=dev)
+        dist.broadcast(flag, src=0)
+        if not int(flag.item()):
             return
-        n = _model._lib.load().tg_net_blob_floats_arch(wk.S, wk.config.encode_state_channels, wk.filters, wk.arch.code.encode())
-        blob = _model.pack_weights(w, wk.S, wk.config.encode_state_channels, wk.filters, arch=wk.arch) if w is not None \
-            else np.zeros(n, np.float32)
-        blob = broadcast_weights(blob, src=0, device=dev)
-        wk.set_weights_blob(blob)
-        self._weights_version = id(w) if w is not None else object()
+        if rank != 0:
+            if int(flag.item()) == 2 and not wk.arch.policy_attention:
+                wk.arch = _model.transgo_arch()
+            n = _model._lib.load().tg_net_blob_floats_arch(wk.S, wk.config.encode_state_channels, wk.filters, wk.arch.code.encode())
+            blob = np.zeros(n, np.float32)
+        wk.set_weights_blob(broadcast_weights(blob, src=0, device=dev))
 
     def policy_evaluate(self, n_games=10, shared_storage_worker=None, seed=0):
         """New-vs-old evaluation matches (self_play.py:986-1040): the train model ("weights") against the evaluation model
@@ -258,19 +303,38 @@ class SelfPlay:
         return win_ratio, info2, info3
 
     def continuous_self_play(self, shared_storage_worker, mem, max_moves=None):
+        """self_play.py:902-983 for G games per rank at once.  Finished games are gathered to rank 0
+        (transgo_amd.distributed.gather_harvest: the RCCL exchange that replaces the per-tuple Ray RPCs of :956,:965) and only
+        rank 0 appends.  `mem` is either a device store (DeviceReplayMemory: the batch goes HBM -> HBM) or anything with the
+        reference's append(obs, pi, z, own) (replay_buffer.py:30-34), which receives the reference's 8 tuples per move in
+        the reference's order.  Counters: now_play_steps += 1 per move per game, now_play_games += 1 per finished game."""
+        from .distributed import gather_harvest
+        dist, multi, rank, world = self._dist()
+        owner = rank == 0
+        device_mem = hasattr(mem, "append_harvest")
+        on_gpu = device_mem or (multi and dist.get_backend() == "nccl")
+        wk = self.worker
         moves = 0
         while max_moves is None or moves < max_moves:
             start = time.time()
             self._refresh_weights(shared_storage_worker)
-            finished = self.worker.step()
-            for _ in range(self.worker.G):
-                _call(shared_storage_worker.set_info, "now_play_steps")           # self_play.py:928
-            for rec in finished:
-                for tup in self.worker.targets(rec):
-                    _call(mem.append, *tup)                                       # self_play.py:956, :965
-                _call(shared_storage_worker.set_info, "now_play_games")           # self_play.py:967
+            h = wk.advance(device=on_gpu)
+            batches = gather_harvest(h, wk.S, wk.config.encode_state_channels, dst=0, device_index=wk.device) if multi \
+                else ([h] if h is not None else [])
             moves += 1
-            while (finished and                                                   # self_play.py:970-980
+            if not owner:
+                continue
+            _bump(shared_storage_worker, "now_play_steps", wk.G * world)              # self_play.py:928
+            finished = 0
+            for hb in batches:
+                if device_mem:
+                    mem.append_harvest(hb)
+                else:
+                    for tup in hb.targets():
+                        _call(mem.append, *tup)                                       # self_play.py:956, :965
+                finished += hb.n_games
+            _bump(shared_storage_worker, "now_play_games", finished)                  # self_play.py:967
+            while (finished and                                                       # self_play.py:970-980
                    _get(_call(shared_storage_worker.get_info, "now_train_steps"))
                    / max(1, _get(_call(shared_storage_worker.get_info, "now_play_steps")))
                    < _get(_call(shared_storage_worker.get_info, "train_play_ratio"))

@@ -11,7 +11,7 @@ visit counts -> pi and sampled move on the host, the move's record entry + re-ro
 move finished: scoring + target generation on the device (tg_sp_harvest), the gather to rank 0 (RCCL, device buffers) and
 the append into the device-resident replay store (tg_replay_append_dev), then the restart of their slots.
 The boards are staggered before the warm-up (slot g is g mod max_step plies into its game, reached by real self-play with
-8-simulation searches), so the timed steps see the steady state of a running pipeline: ~G/max_step games finish on every
+16-simulation searches), so the timed steps see the steady state of a running pipeline: ~G/max_step games finish on every
 step.  Boards live in HBM throughout; per step the host receives G*(A+1) int32 visit counts and sends G actions.
 `value` = completed simulations (root visit increments) of all ranks / max-over-ranks wall time; `games_per_hour` =
 games finished (and stored) inside the timed region / the same wall time.
@@ -132,7 +132,7 @@ def kernel_name(S, filters, dtype):
     return f"k_conv3x3<{S},{filters},{filters}> (fp32 MFMA 16x16x4 implicit GEMM)"
 
 
-def stagger(sp, period, sims=8):
+def stagger(sp, period, sims=16):
     """Put slot g exactly (g mod period) plies into its game by real self-play with cheap searches: `period - 1` untimed moves
     of every board, slot g restarted (fresh seed, empty board, empty record) just before the move that leaves it at its
     offset.  Every record entry the timed steps later harvest was written by the engine's own tg_sp_play."""
@@ -292,7 +292,7 @@ def main():
                        "step": "one move of every board (search + move selection + record + re-root) and, for the games it "
                                "finishes, device-side target generation, gather to rank 0 and append to the device replay store",
                        "stagger": (f"slot g starts the warm-up g mod {period} plies into its game ({period - 1} untimed moves "
-                                   f"with 8-simulation searches, {stagger_s:.1f} s)") if period > 1 else "none: all boards start together"},
+                                   f"with 16-simulation searches, {stagger_s:.1f} s)") if period > 1 else "none: all boards start together"},
             "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(conv_tflops / peak, 4), "traffic": traffic,
                          "traffic_note": (f"HBM bytes per full-batch launch, FETCH_SIZE x2 + WRITE_SIZE (profiles/{os.path.basename(tfile)})"

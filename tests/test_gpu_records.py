@@ -38,7 +38,7 @@ def _play_and_assemble(eng, seeds, moves):
     return finished, batches
 
 
-@pytest.mark.parametrize("S,G,sims,max_step", [(9, 7, 24, 14), (19, 3, 12, 9)])
+@pytest.mark.parametrize("S,G,sims,max_step", [(9, 7, 24, 14), (19, 3, 64, 9)])
 def test_device_records_equal_host_assembled_records(S, G, sims, max_step):
     from transgo_amd.engine import SelfPlayEngine
     from transgo_amd.self_play import game_targets
@@ -122,9 +122,9 @@ def _actor_worker(rank, world, port, q, backend):
                                 device_id=torch.device("cuda", gpu))
     else:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    cfg = Config(num_simulation=8, max_step=5, buffer_size=8 * 1024)
+    cfg = Config(num_simulation=24, max_step=5, buffer_size=8 * 1024)
     G = 3 + rank                                                     # ragged shards
-    actor = SelfPlay(cfg, n_games=G, device=gpu, rank=rank, world=world, evaluator=evaluators.flat)
+    actor = SelfPlay(cfg, n_games=G, device=gpu, rank=rank, world=world, evaluator=evaluators.sharp)
     st = mem = None
     if rank == 0:
         st = SharedStorage({"weights": None, "now_play_steps": 0, "now_play_games": 0, "now_train_steps": 10 ** 9,
@@ -132,7 +132,7 @@ def _actor_worker(rank, world, port, q, backend):
                             "adjust_lr": False, "learn_rate": 1e-4}, cfg)
         mem = DeviceReplayMemory(cfg, capacity_positions=1024, device=gpu) if backend == "nccl" else ReplayMemory_Random(cfg)
     actor.continuous_self_play(st, mem, max_moves=11)                # 2 full generations (5 moves each) + 1 move
-    out = {"rank": rank, "finished_local": actor.worker.games_finished, "G": G}
+    out = {"rank": rank, "finished_local": actor.worker.games_finished, "G": G, "dropped": actor.worker.games_dropped}
     if rank == 0:
         info = mem.info()
         out.update(steps=st.get_info("now_play_steps"), games=st.get_info("now_play_games"),
@@ -152,6 +152,7 @@ def _run_actor_ranks(backend):
     [p.join(120) for p in ps]
     assert all(p.exitcode == 0 for p in ps)
     r0, r1 = res
+    assert r0["dropped"] == r1["dropped"] == 0
     assert r0["finished_local"] == 2 * 3 and r1["finished_local"] == 2 * 4
     assert r0["games"] == 14                                          # every rank's finished games reached the owner
     assert r0["entries"] == 14 * 5 * 8                                # 5 positions per game, 8 reference entries per position

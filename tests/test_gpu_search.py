@@ -164,7 +164,7 @@ def test_arena_overflow_parks_the_game_and_the_slot_restarts():
     """A deliberately tiny tree arena: the overflowing games are parked (no out-of-bounds write, no endless search, no
     exception), tg_sp_play reports them, the other entry points stay usable, and resetting the slots starts new games."""
     from transgo_amd.engine import SelfPlayEngine
-    eng = SelfPlayEngine(4, num_simulation=64, evaluator=evaluators.flat, arena_slots=4 * 84 + 16)
+    eng = SelfPlayEngine(4, num_simulation=64, evaluator=evaluators.flat, arena_slots=6 * 84 + 16)
     eng.reset(np.arange(4))
     eng.search()                                               # the search ends: parked games are not active
     err = eng.game_errors()
@@ -175,7 +175,7 @@ def test_arena_overflow_parks_the_game_and_the_slot_restarts():
     assert eng.harvest() is None                               # parked games are not finished games
     eng.reset(np.arange(10, 14), eng.errored)                  # new games in the same slots
     assert eng.stats()["errors"] == 0 and not eng.errored.any()
-    eng.search(num_simulation=2)                               # 2 simulations fit even this arena
+    eng.search(num_simulation=2)                               # one wave (R = 4 read-outs = 4 blocks) fits even this arena
     assert eng.stats()["errors"] == 0
     eng.close()
 

@@ -93,6 +93,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and libtransgo_hip links the system one under the
+    # same SONAME, so whichever is mapped first serves both.  torch cannot enumerate devices through the system runtime
+    # ("No HIP GPUs are available"), the library runs fine on torch's -- so when torch is installed it is imported first.
+    # (A plain-C host, examples/c_host_min.c, never loads torch and uses the system runtime.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise TransgoError(f"{LIB_PATH} not found: build it with `make -C transgo_amd/csrc` "
                            "(or python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")

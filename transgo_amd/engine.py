@@ -49,6 +49,12 @@ def choose_moves_batch(visits, steps, u, live, selfplay=True):
         return actions, pis
     counts = visits[idx].astype(np.int64)
     counts = np.where(counts == 1, 0, counts)
+    # No child visited twice (only possible when num_simulation is far below the number of legal moves): the reference
+    # divides 0 by 0 here and np.random.choice raises on the NaN probabilities (self_play.py:671-683).  A batched engine
+    # cannot afford one degenerate board stopping thousands, so such a row keeps its raw counts instead.
+    dead = np.sum(counts, axis=1) == 0
+    if dead.any():
+        counts[dead] = visits[idx][dead]
     pis[idx] = counts / np.sum(counts, axis=1)[:, None]
     inv_tau = np.array([1.0 / (temperature(int(s)) if selfplay else 0.12) for s in steps[idx]])
     powed = np.power(counts, inv_tau[:, None])

@@ -149,6 +149,11 @@ int tg_sp_root_info(tg_ctx* ctx, int32_t* visits /*[G][A]*/, int32_t* root_n, in
 /* One random_sample() from each game's stream: the draw inside np.random.choice(A, p=) (self_play.py:683). */
 int tg_sp_draw_uniform(tg_ctx* ctx, double* u /*[G]*/, const uint8_t* mask);
 int tg_sp_rng_state(tg_ctx* ctx, int game, tg_mt19937* out);
+/* All G streams at once, and the way back (mask NULL = all): lets a game's stream move between contexts -- in policy_evaluate
+ * (self_play.py:986-1040) the two agents of a game draw from ONE global stream, so it follows the game from the engine holding
+ * the train model to the one holding the evaluation model and back, ply by ply. */
+int tg_sp_rng_get(tg_ctx* ctx, tg_mt19937* out /*[G]*/);
+int tg_sp_rng_set(tg_ctx* ctx, const tg_mt19937* in /*[G]*/, const uint8_t* mask /*[G] or NULL*/);
 /* update_with_action (self_play.py:857-872) for every unfinished game; done[g] = 1 game over, 2 the game is parked in
  * error (tree arena overflow; see tg_sp_game_errors), 0 otherwise.  With cfg.record_games the move's record entry is
  * written first (self_play.py:917-926).  Leaves a root batch pending for the games whose new root was not yet expanded. */
@@ -232,6 +237,9 @@ uint32_t tg_host_mt_next32(tg_mt19937* s);
 double tg_host_mt_random_sample(tg_mt19937* s);                     /* random_sample(): the draw inside choice(A, p=) (self_play.py:683) */
 int32_t tg_host_mt_choice_index(tg_mt19937* s, int32_t k);          /* index drawn by choice(list of k) (self_play.py:709) */
 int tg_host_mt_dirichlet(tg_mt19937* s, double alpha, int32_t n, double* out);   /* dirichlet([alpha]*n) (self_play.py:93) */
+/* getSubEncode (go_env.h:70, board.cc:1166-1271) with the board size as an argument: crops channels x S x S 32-bit planes into
+ * cut_num (<= 5) channels x s x s windows -- the four corners, then the centre.  Host arrays; no GPU needed. */
+void tg_host_sub_encode(int board_size, const void* encode, void* sub_encode, int sub_board_size, int channels, int cut_num);
 
 
 /* ---- 4. the reference engine's own 15 entry points (GoEnv/cpp_src/go_env.h:24-70), same names and signatures -------------

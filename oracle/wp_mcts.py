@@ -224,3 +224,26 @@ def targets_for_game(env, final_state, observations, pis, players, board_size=9)
             fo = np.array([np.fliplr(pl) for pl in ro])
             out.append((fo, np.append(np.fliplr(rp).flatten(), pass_p), zz, np.fliplr(rw).flatten()))
     return out
+
+
+def policy_evaluate(env, evaluate_train, evaluate_eval, n_games, seed, num_simulation=210, board_size=9):
+    """SelfPlay.policy_evaluate (self_play.py:986-1040): n_games between the train agent and the evaluation agent, the train
+    agent's colour alternating from BLACK, every move by select_action; both agents draw from one stream (the reference's
+    global np.random).  The reference never seeds; the parity harness seeds the stream with seed + i at the start of game i.
+    Returns (winners[n_games], colours[n_games], win_ratio)."""
+    BLACK, WHITE = 1, 2
+    color = BLACK
+    winners, colours = [], []
+    for i in range(n_games):
+        rng = np.random.RandomState(int(seed + i) % (2 ** 32))
+        train = OracleSearch(env, evaluate_train, rng, num_simulation=num_simulation, board_size=board_size)
+        evalu = OracleSearch(env, evaluate_eval, rng, num_simulation=num_simulation, board_size=board_size)
+        bots = {BLACK: train, WHITE: evalu} if color == BLACK else {BLACK: evalu, WHITE: train}
+        state, done = env.reset()
+        while not done:
+            action = bots[env.getPlayer(state)].select_action(state)
+            state, done = env.step(state, action)
+        winners.append(env.getWinner(state)); colours.append(color)
+        color = BLACK + WHITE - color
+    winners, colours = np.array(winners), np.array(colours)
+    return winners, colours, float((winners == colours).sum()) / n_games

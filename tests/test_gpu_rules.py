@@ -169,6 +169,8 @@ def test_compat_abi_in_lockstep_with_the_compiled_reference():
     if not os.path.exists(ref_so):
         pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
     libs = [ctypes.CDLL(ref_so), ctypes.CDLL(_lib.LIB_PATH)]
+    from transgo_amd.environment import GoEnv
+    mirror = GoEnv()                                         # the Python mirror's subEncode (environment.py:110-113) rides along
     for L in libs:
         L.Init.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float]
         for f in ("Step", "Step_", "checkAction", "isTerminated", "Reset", "Encode"):
@@ -196,6 +198,7 @@ def test_compat_abi_in_lockstep_with_the_compiled_reference():
                 outs.append((list(la[:n1]), list(ne[:n2]), enc, float(L.getScore(s)), float(sc2), ter, sub, chk,
                              L.getPlayer(s) & 0xFF, L.getStep(s), bool(L.isTerminated(s))))
             a, b = outs
+            assert np.array_equal(mirror.subEncode(a[2].reshape(10, 9, 9)).reshape(-1), a[6][:4 * 10 * 49]), (g, "GoEnv.subEncode")
             for i, (x, y) in enumerate(zip(a, b)):
                 assert np.array_equal(np.asarray(x), np.asarray(y)), (g, "field", i)
             calls += 1

@@ -160,6 +160,32 @@ def test_policy_evaluate_runs_matches_and_reports():
         assert st.get_info("evaluate_score") == 100
 
 
+def test_policy_evaluate_equals_the_oracle_twin():
+    """SelfPlay.policy_evaluate (all games concurrently, two engines, per-game streams handed between them ply by ply) against
+    the oracle's sequential restatement of self_play.py:986-1040 with the same per-game seeds: identical winners game by game,
+    identical win ratio, identical promotion.  Odd n_games on purpose (the last game is an even one: info2's line)."""
+    from oracle.go_oracle import OracleGoEnv
+    from oracle.wp_mcts import policy_evaluate as oracle_policy_evaluate
+    from transgo_amd.configure import Config
+    from transgo_amd.self_play import SelfPlay
+    from transgo_amd.shared_storage import SharedStorage
+    cfg = Config(num_simulation=24, max_step=16)
+    for fns, n_games, seed in (((evaluators.sharp, evaluators.flat), 5, 300), ((evaluators.flat, evaluators.sharp), 4, 77)):
+        st = SharedStorage({"weights": "new", "evaluate_weights": "old", "evaluate_score": 100}, cfg)
+        sp = SelfPlay(cfg, n_games=2, evaluator=evaluators.flat)
+        ratio, info2, info3 = sp.policy_evaluate(n_games, st, seed=seed, evaluators={"train": fns[0], "eval": fns[1]})
+        w, c, want = oracle_policy_evaluate(OracleGoEnv(max_step=16), fns[0], fns[1], n_games, seed, num_simulation=24)
+        assert list(sp.last_evaluation["winners"]) == list(w) and list(sp.last_evaluation["colours"]) == list(c)
+        assert ratio == want
+        assert info2 == "simulate round: {},  winer is : {},  model player is : {}\n".format(n_games, int(w[-1]), int(c[-1]))
+        assert info3 == "evaluate_score:100, win: {}, lose: {}\n".format(int((w == c).sum()), int((w != c).sum()))
+        if want == 1:
+            assert st.get_info("evaluate_score") == 200 and st.get_info("evaluate_weights") == "new"
+        else:
+            assert st.get_info("evaluate_score") == 100 and st.get_info("evaluate_weights") == "old"
+        sp.worker.engine.close()
+
+
 def test_arena_overflow_parks_the_game_and_the_slot_restarts():
     """A deliberately tiny tree arena: the overflowing games are parked (no out-of-bounds write, no endless search, no
     exception), tg_sp_play reports them, the other entry points stay usable, and resetting the slots starts new games."""

@@ -57,6 +57,8 @@ SIGNATURES = {
     "tg_sp_root_info": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "tg_sp_draw_uniform": (ctypes.c_int, [_vp, _vp, _vp]),
     "tg_sp_rng_state": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(TgMt19937)]),
+    "tg_sp_rng_get": (ctypes.c_int, [_vp, _vp]),
+    "tg_sp_rng_set": (ctypes.c_int, [_vp, _vp, _vp]),
     "tg_sp_play": (ctypes.c_int, [_vp, _vp, _vp]),
     "tg_sp_final": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "tg_sp_game_errors": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _vp]),
@@ -84,6 +86,7 @@ SIGNATURES = {
     "tg_host_mt_next32": (ctypes.c_uint32, [ctypes.POINTER(TgMt19937)]),
     "tg_host_mt_random_sample": (ctypes.c_double, [ctypes.POINTER(TgMt19937)]),
     "tg_host_mt_choice_index": (ctypes.c_int32, [ctypes.POINTER(TgMt19937), ctypes.c_int32]),
+    "tg_host_sub_encode": (None, [ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "tg_host_mt_dirichlet": (ctypes.c_int, [ctypes.POINTER(TgMt19937), ctypes.c_double, ctypes.c_int32, _vp]),
 }
 

@@ -128,7 +128,14 @@ void Show(const void* state) {                                                  
 // branch (self_play.py:806).
 void getSubEncode(int* encode_state, int* sub_encode_state, int sub_board_size, int encode_state_channels, int cut_num) {
     cfg_defaults();
-    const int S = g_cfg.board_size, s = sub_board_size, C = encode_state_channels, iv = S - s, ter = iv / 2;
+    tg_host_sub_encode(g_cfg.board_size, encode_state, sub_encode_state, sub_board_size, encode_state_channels, cut_num);
+}
+
+// The same with the board size as an argument (the reference's is a compile-time constant): what GoEnv.subEncode
+// (environment.py:110-113) calls.
+void tg_host_sub_encode(int board_size, const void* encode, void* sub_encode, int sub_board_size, int channels, int cut_num) {
+    const int32_t* encode_state = (const int32_t*)encode; int32_t* sub_encode_state = (int32_t*)sub_encode;
+    const int S = board_size, s = sub_board_size, C = channels, iv = S - s, ter = iv / 2;
     const int ox[5] = {0, iv, 0, iv, ter}, oy[5] = {0, 0, iv, iv, ter};
     for (int i = 0; i < cut_num && i < 5; ++i)
         for (int c = 0; c < C; ++c)

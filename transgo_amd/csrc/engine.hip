@@ -913,6 +913,25 @@ int tg_sp_rng_state(tg_ctx* ctx, int game, tg_mt19937* out) {
     return TG_OK;
 }
 
+int tg_sp_rng_get(tg_ctx* ctx, tg_mt19937* out) {
+    NEED_ENGINE(ctx);
+    if (!out) return TG_ERR_ARG;
+    int rc = rng_to_host(ctx);
+    if (rc) return rc;
+    memcpy(out, ctx->eng->h_rng, sizeof(tg_mt19937) * (size_t)ctx->eng->G);
+    return TG_OK;
+}
+
+int tg_sp_rng_set(tg_ctx* ctx, const tg_mt19937* in, const uint8_t* mask) {
+    NEED_ENGINE(ctx);
+    if (!in) return TG_ERR_ARG;
+    Engine* e = ctx->eng;
+    int rc = rng_to_host(ctx);                                         // the host mirror becomes (stays) the authoritative copy
+    if (rc) return rc;
+    for (int g = 0; g < e->G; ++g) if (!mask || mask[g]) e->h_rng[g] = in[g];
+    return TG_OK;
+}
+
 int tg_sp_play(tg_ctx* ctx, const int32_t* actions, uint8_t* done) {
     NEED_ENGINE(ctx);
     Engine* e = ctx->eng;

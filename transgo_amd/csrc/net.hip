@@ -51,6 +51,13 @@ struct Net {
     float* hc = nullptr;   // [rows][P][16] head conv output
     float* own = nullptr;  // [rows][P]
     int rows_cap = 0;
+    // Two complete weight sets (f2, "double-buffered so search never stalls"): the forward pass reads set `active` (the pointer
+    // fields above are bound to it); a refresh fills the other one -- tg_net_load_async on a side stream while searches keep
+    // running -- and the next forward that finds it complete rebinds.  `swapped` orders a later refill of the retired set behind
+    // every kernel that may still read it.
+    struct WeightSet { float* blob = nullptr; float* wstage = nullptr; _Float16* wh = nullptr; _Float16* stem_h = nullptr; _Float16* head_h = nullptr; };
+    WeightSet sets[2]; int active = 0; bool pending = false;
+    hipStream_t side = nullptr; hipEvent_t loaded = nullptr, swapped = nullptr; float* pinned = nullptr;
     // profiling of the dominant kernel (3x3 conv F->F) with HIP events on the launch stream
     bool prof = false; std::vector<hipEvent_t> ev; size_t ev_used = 0; double conv_ms = 0; long conv_launches = 0; double conv_flops = 0;
 };

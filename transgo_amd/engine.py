@@ -237,6 +237,18 @@ class SelfPlayEngine:
         self.ctx.call("tg_sp_rng_state", int(game), ctypes.byref(s))
         return np.frombuffer(s.key, np.uint32).copy(), int(s.pos)
 
+    def rng_streams(self):
+        """All G MT19937 streams as a uint8 array [G][sizeof(tg_mt19937)] (opaque; hand it to set_rng_streams)."""
+        out = np.zeros((self.G, ctypes.sizeof(_lib.TgMt19937)), np.uint8)
+        self.ctx.call("tg_sp_rng_get", _ptr(out))
+        return out
+
+    def set_rng_streams(self, streams, mask=None):
+        st = np.ascontiguousarray(streams, np.uint8)
+        assert st.shape == (self.G, ctypes.sizeof(_lib.TgMt19937))
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self.ctx.call("tg_sp_rng_set", _ptr(st), _ptr(m))
+
     def stats(self):
         v = [ctypes.c_uint64() for _ in range(4)]; e = ctypes.c_int32(); m = ctypes.c_int32()
         self.ctx.call("tg_sp_stats", *[ctypes.byref(x) for x in v], ctypes.byref(e), ctypes.byref(m))

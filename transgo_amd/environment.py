@@ -82,6 +82,12 @@ class GoEnv:
     def encode(self, state):                                  # environment.py:105-108
         return self.query_batch(self._one(state), obs=True)["obs"][0]
 
+    def subEncode(self, encode):                              # environment.py:110-113 (only the dead sub_model branch calls it)
+        encode = np.ascontiguousarray(encode, np.float32)
+        sub_encode = np.zeros([4, self.encoded_dim, self.sub_board_size, self.sub_board_size], dtype="float32")
+        self.ctx.lib.tg_host_sub_encode(self.board_size, _ptr(encode), _ptr(sub_encode), self.sub_board_size, self.encoded_dim, 4)
+        return sub_encode
+
     def getScore(self, state):                                # environment.py:115-116
         return float(self.query_batch(self._one(state), score=True)["score"][0])
 

@@ -244,32 +244,44 @@ class SelfPlay:
             blob = np.zeros(n, np.float32)
         wk.set_weights_blob(broadcast_weights(blob, src=0, device=dev))
 
-    def policy_evaluate(self, n_games=10, shared_storage_worker=None, seed=0):
+    def policy_evaluate(self, n_games=10, shared_storage_worker=None, seed=0, evaluators=None):
         """New-vs-old evaluation matches (self_play.py:986-1040): the train model ("weights") against the evaluation model
         ("evaluate_weights"), colours alternating game by game, every move by select_action (fresh tree, no noise,
         temperature 0.12).  All n_games run concurrently: two engines (one per weight set) each move half of the games per
-        ply.  Returns (win_ratio, info2, info3) and promotes the weights on a clean sweep exactly as the reference does."""
+        ply.  In the reference both agents of a game draw from the one global NumPy stream; here game i owns a stream seeded
+        `seed + i` that travels with the game between the two engines, so a game equals the reference's game i played after
+        np.random.seed(seed + i) (tests/test_gpu_search.py checks that against the oracle).  Returns (win_ratio, info2, info3)
+        and promotes the weights on a clean sweep exactly as the reference does.  `evaluators` = {"train": fn, "eval": fn}
+        replaces the two networks by host evaluators (parity tests)."""
+        from . import _lib
         from .environment import GoEnv
         cfg, w = self.config, self.worker
         arch = w.arch
         half = (n_games + 1) // 2
-        mk = lambda: SelfPlayEngine(
+        mk = lambda who: SelfPlayEngine(
             half, board_size=cfg.board_size, num_simulation=cfg.num_simulation, parallel_readouts=cfg.parallel_readouts,
             c_puct1=cfg.c_puct1, c_puct2=cfg.c_puct2, wu_loss=cfg.wu_loss, komi=cfg.komi, max_step=cfg.max_step,
             encode_dim=cfg.encode_state_channels, net_blocks=w.blocks, net_filters=w.filters, device=w.device,
-            net_precision=getattr(cfg, "inference_dtype", "f32"))
-        eng = {"train": mk(), "eval": mk()}
-        _model.load_into(eng["train"].ctx, _get(_call(shared_storage_worker.get_info, "weights")), cfg.board_size,
-                         cfg.encode_state_channels, w.filters, arch=arch)
-        _model.load_into(eng["eval"].ctx, _get(_call(shared_storage_worker.get_info, "evaluate_weights")), cfg.board_size,
-                         cfg.encode_state_channels, w.filters, arch=arch)
-        for k, e in enumerate(eng.values()):
-            e.reset(np.arange(half) + seed + 7919 * k)            # seeds the per-game RNG streams
+            net_precision=getattr(cfg, "inference_dtype", "f32"), evaluator=evaluators[who] if evaluators else None)
+        eng = {"train": mk("train"), "eval": mk("eval")}
+        if not evaluators:
+            for who, key in (("train", "weights"), ("eval", "evaluate_weights")):
+                _model.load_into(eng[who].ctx, _get(_call(shared_storage_worker.get_info, key)), cfg.board_size,
+                                 cfg.encode_state_channels, w.filters, arch=arch)
+        for e in eng.values():
+            e.reset(np.zeros(half, np.uint32))                     # brings the engine up; the streams that count are set per ply
         env = GoEnv(cfg, device=w.device)
-        # game i: train model plays BLACK when i is even (self_play.py:1000,1026)
+        # game i: train model plays BLACK when i is even (self_play.py:1000,1026); group A = even games, B = odd games
         groups = {"A": np.arange(0, n_games, 2), "B": np.arange(1, n_games, 2)}
         states = {g: env.reset_batch(half) for g in groups}
         done = {g: np.arange(half) >= len(idx) for g, idx in groups.items()}
+        streams = {}
+        lib = _lib.load()
+        for g, idx in groups.items():                              # np.random.seed(seed + i) for game i
+            st = (_lib.TgMt19937 * half)()
+            for k, i in enumerate(idx):
+                lib.tg_host_mt_seed(st[k], int(seed + i) % (2 ** 32))
+            streams[g] = np.frombuffer(st, np.uint8).reshape(half, -1).copy()
         ply = 0
         while not (done["A"].all() and done["B"].all()):
             black_is_train_group = "A" if ply % 2 == 0 else "B"      # whose train model is to move at this ply
@@ -277,21 +289,25 @@ class SelfPlay:
                 live = ~done[grp]
                 if not live.any():
                     continue
+                eng[who].set_rng_streams(streams[grp])
                 acts = eng[who].select_action(states[grp], live)
+                streams[grp] = eng[who].rng_streams()
                 nxt, d, _ = env.step_batch(states[grp], np.where(live, acts, cfg.board_size ** 2))
                 states[grp][live] = nxt[live]
                 done[grp] |= d & live
             ply += 1
-        win_num = 0
-        info2 = None
-        for grp, colour in (("A", 1), ("B", 2)):
+        winners = np.zeros(n_games, np.int64)
+        colours = np.where(np.arange(n_games) % 2 == 0, 1, 2)         # the train model's colour in game i
+        for grp in groups:
             n = len(groups[grp])
-            score = env.query_batch(states[grp][:n], score=True)["score"] if n else []
-            for k in range(n):
-                winner = 1 if score[k] > 0 else 2                     # environment.py:118-119
-                win_num += int(winner == colour)
-                info2 = "simulate round: {},  winer is : {},  model player is : {}\n".format(int(groups[grp][k]) + 1, winner, colour)
+            if n:
+                score = env.query_batch(states[grp][:n], score=True)["score"]
+                winners[groups[grp]] = np.where(score > 0, 1, 2)      # environment.py:118-119
+        win_num = int((winners == colours).sum())
         lose_num = n_games - win_num
+        self.last_evaluation = {"winners": winners, "colours": colours}
+        info2 = "simulate round: {},  winer is : {},  model player is : {}\n".format(n_games, int(winners[-1]), int(colours[-1])) \
+            if n_games else None                                      # the reference keeps the last game's line only
         evaluate_score = _get(_call(shared_storage_worker.get_info, "evaluate_score"))
         info3 = "evaluate_score:{}, win: {}, lose: {}\n".format(evaluate_score, win_num, lose_num)
         win_ratio = win_num / n_games

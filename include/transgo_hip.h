@@ -202,6 +202,14 @@ int tg_net_load(tg_ctx* ctx, const float* blob, size_t n_floats, int rows_cap);
  * MainNetwork (model.py:49-76) is "RARRRARRRRAR+P"; tg_net_load uses cfg.net_blocks x 'R'.  Attention needs 9x9. */
 size_t tg_net_blob_floats_arch(int board_size, int encode_dim, int filters, const char* arch);
 int tg_net_load_arch(tg_ctx* ctx, const char* arch, const float* blob, size_t n_floats, int rows_cap);
+/* Weight refresh that never stalls a search (the hand-off of trainer.py:76-79 -> self_play.py:913): there are two complete
+ * weight sets; this call copies the blob to pinned memory and uploads + re-stages it into the idle set on a side stream, then
+ * returns.  Searches keep running on the live set; the first network forward that finds the upload complete switches over.
+ * Falls back to the synchronous load when no network of this architecture is loaded yet.  One refresh in flight at a time (a
+ * second call first waits for the previous one).  tg_net_load_poll: pending = 1 while a refresh is not adopted yet; wait != 0
+ * blocks until it is. */
+int tg_net_load_async(tg_ctx* ctx, const char* arch, const float* blob, size_t n_floats);
+int tg_net_load_poll(tg_ctx* ctx, int wait, int* pending);
 /* main_prediction (model.py:17-20) on host buffers: obs f32[n][C][S][S] -> policy f32[n][A] (softmax), value f32[n]
  * (tanh), own f32[n][S*S] (tanh; may be NULL). */
 int tg_net_predict(tg_ctx* ctx, const float* obs, int n_rows, float* policy, float* value, float* own);

@@ -160,3 +160,34 @@ def test_fp16_refused_where_not_built():
     h = HipNetwork(9, 10, 64, 2, rows_cap=8, precision="f16")
     with pytest.raises(TransgoError):
         h.set_weights(random_weights(9, 10, 64, 2))
+
+
+@pytest.mark.parametrize("precision,F", [("f32", 128), ("f16", 128), ("f32", 32)])
+def test_background_weight_refresh_switches_sets_cleanly(precision, F):
+    """tg_net_load_async (trainer.py:76-79 -> self_play.py:913): the refresh goes into the idle weight set on a
+    side stream; until it is adopted every forward still computes with the old weights, afterwards with exactly the new ones
+    (bit-identical to a context that loaded them synchronously).  Three refreshes in a row reuse both sets."""
+    import ctypes
+    from transgo_amd import model
+    from transgo_amd.model import HipNetwork
+    x = _positions(9, 40, 17)
+    sds = [model.random_weights(9, 10, F, 2, seed=s) for s in (1, 2, 3, 4)]
+    want = []
+    for sd in sds:
+        h = HipNetwork(9, 10, F, 2, rows_cap=64, precision=precision)
+        h.set_weights(sd)
+        want.append(h.main_prediction(x))
+        h.ctx.close()
+    h = HipNetwork(9, 10, F, 2, rows_cap=64, precision=precision)
+    h.set_weights(sds[0])
+    same = lambda a, b: all(np.array_equal(p, q) for p, q in zip(a, b))
+    assert same(h.main_prediction(x), want[0])
+    for k in (1, 2, 3):
+        blob = model.pack_weights(sds[k], 9, 10, F, arch=h.arch)
+        h.ctx.call("tg_net_load_async", h.arch.code.encode(), blob.ctypes.data_as(ctypes.c_void_p), blob.size)
+        got = h.main_prediction(x)                        # may run before or after the switch, never on a half-written set
+        assert same(got, want[k - 1]) or same(got, want[k])
+        pend = ctypes.c_int(-1)
+        h.ctx.call("tg_net_load_poll", 1, ctypes.byref(pend))
+        assert pend.value == 0
+        assert same(h.main_prediction(x), want[k])

@@ -16,6 +16,7 @@
 // into its weights/bias, BN that precedes one (pre-activation) is applied with ReLU while the tile is staged into LDS.
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -1142,9 +1143,12 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
     return TG_OK;
 }
 
+int adopt_pending(tg_ctx* ctx, Net* n, bool wait);
+
 int forward(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, float* value, float* own) {
     if (rows <= 0) return TG_OK;
     if (rows > n->rows_cap) TG_FAIL(ctx, TG_ERR_ARG, "network batch larger than the allocated activation buffers");
+    { int rc = adopt_pending(ctx, n, /*wait=*/false); if (rc) return rc; }      // a finished background refresh takes over here
 #define TG_NET_CASE(SZ, FF) if (n->S == SZ && n->F == FF) return forward_t<SZ, FF>(ctx, n, obs, rows, policy, value, own)
     TG_NET_CASE(9, 32); TG_NET_CASE(9, 64); TG_NET_CASE(9, 128); TG_NET_CASE(9, 256);
     TG_NET_CASE(19, 128); TG_NET_CASE(19, 256);
@@ -1178,6 +1182,81 @@ size_t expected_floats(int S, int C, int F, const std::string& arch) {
     n += 9 * 16 * (size_t)F + 16;
     n += 2 * P * 64 + 64 + 64 + 1 + 64 * P + P + 4 * P * A + A;
     return n;
+}
+
+// Bind the pointer fields of `n` to weight set `k` (blob sections in the order transgo_amd/model.py:pack_weights writes them).
+void bind_weights(Net* n, int k) {
+    const int F = n->F; const size_t P = n->P, A = n->A, Wq = (size_t)F / 4 * 2 + F;
+    const Net::WeightSet& w = n->sets[k];
+    n->blob = w.blob; n->wstage = w.wstage; n->wh = w.wh; n->stem_h = w.stem_h; n->head_h = w.head_h;
+    std::string trunk; bool pol = false;
+    parse_arch(n->arch, &trunk, &pol);
+    const float* p = w.blob;
+    auto take = [&](size_t c) { const float* q = p; p += c; return q; };
+    auto take_att = [&](AttW& a) { a.qkv.w = take(Wq * F); a.qkv.b = take(Wq); a.gamma = take(1); a.s = take(F); a.t = take(F); };
+    n->stem.w = take(9 * (size_t)F * 16); n->stem.b = take(F);
+    n->blocks.assign(n->NB, BlockW{});
+    n->layers.clear();
+    const size_t per = 9 * (size_t)F * F;
+    int ri = 0;
+    for (char c : trunk) {
+        Layer L; L.kind = c == 'A'; L.ridx = -1; L.a = AttW{};
+        if (c == 'R') {
+            BlockW& b = n->blocks[ri];
+            b.s1 = take(F); b.t1 = take(F);
+            b.c1.w = take(per); b.c1.b = take(F);
+            b.c2.w = take(per); b.c2.b = take(F);
+            b.g1 = w.wstage ? w.wstage + (size_t)(2 * ri) * per : nullptr; b.g2 = w.wstage ? w.wstage + (size_t)(2 * ri + 1) * per : nullptr;
+            b.h1 = w.wh ? w.wh + (size_t)(2 * ri) * per : nullptr; b.h2 = w.wh ? w.wh + (size_t)(2 * ri + 1) * per : nullptr;
+            L.ridx = ri++;
+        } else {
+            take_att(L.a);
+        }
+        n->layers.push_back(L);
+    }
+    n->s_end = take(F); n->t_end = take(F);
+    if (pol) { take_att(n->patt); n->head_a.w = take(9 * 16 * (size_t)F); n->head_a.b = take(16); }
+    n->head.w = take(9 * 16 * (size_t)F); n->head.b = take(16);
+    n->w_vo = take(2 * P * 64); n->b_vo = take(64); n->w_v = take(64); n->b_v = take(1);
+    n->w_o = take(64 * P); n->b_o = take(P); n->w_a = take(4 * P * A); n->b_a = take(A);
+}
+
+// Upload `blob` into weight set k and rebuild its stage-ordered copies, everything on `st` (no synchronisation here).
+int fill_weight_set(tg_ctx* ctx, Net* n, int k, const float* blob, hipStream_t st) {
+    const int F = n->F;
+    TG_HIP(ctx, hipMemcpyAsync(n->sets[k].blob, blob, sizeof(float) * n->blob_floats, hipMemcpyHostToDevice, st));
+    Net view = *n;                                        // pointer fields of set k without disturbing the live binding
+    bind_weights(&view, k);
+    if (n->prec == 1) {
+        // stage-ordered fp16 copies, converted on the device from the blob just uploaded (round to nearest even)
+        for (const BlockW& b : view.blocks) {
+            hipLaunchKernelGGL(k_restage_half, dim3(1024), dim3(256), 0, st, b.c1.w, const_cast<_Float16*>(b.h1), F, F, F, 32);   // k_conv3x3_h2: 32-channel stages
+            hipLaunchKernelGGL(k_restage_half, dim3(1024), dim3(256), 0, st, b.c2.w, const_cast<_Float16*>(b.h2), F, F, F, 32);
+        }
+        hipLaunchKernelGGL(k_restage_half, dim3(256), dim3(256), 0, st, view.stem.w, view.stem_h, F, 16, 64, 32);
+        hipLaunchKernelGGL(k_restage_half, dim3(256), dim3(256), 0, st, view.head.w, view.head_h, 16, F, F, 32);
+        TG_HIP(ctx, hipGetLastError());
+    } else if (n->dma) {
+        // stage-ordered copy for k_conv3x3_sg, [slice*9 + tap][cout][16 channels of the slice], made on the device
+        for (const BlockW& b : view.blocks) {
+            hipLaunchKernelGGL(k_restage_f32, dim3(1024), dim3(256), 0, st, b.c1.w, const_cast<float*>(b.g1), F);
+            hipLaunchKernelGGL(k_restage_f32, dim3(1024), dim3(256), 0, st, b.c2.w, const_cast<float*>(b.g2), F);
+        }
+        TG_HIP(ctx, hipGetLastError());
+    }
+    return TG_OK;
+}
+
+// A completed asynchronous refresh becomes the live set: called at the top of every forward pass and of every load.
+int adopt_pending(tg_ctx* ctx, Net* n, bool wait) {
+    if (!n->pending) return TG_OK;
+    if (wait) TG_HIP(ctx, hipEventSynchronize(n->loaded));
+    else if (hipEventQuery(n->loaded) != hipSuccess) return TG_OK;     // still in flight: keep searching on the old weights
+    n->active ^= 1;
+    bind_weights(n, n->active);
+    n->pending = false;
+    TG_HIP(ctx, hipEventRecord(n->swapped, ctx->stream));               // kernels already queued may still read the retired set
+    return TG_OK;
 }
 
 }  // namespace
@@ -1226,7 +1305,6 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
         e->net = n;
         n->S = S; n->P = (int)P; n->A = (int)A; n->C = C; n->F = F; n->NB = NB; n->rows_cap = rows_cap; n->arch = arch; n->pol_att = pol;
         n->blob_floats = n_floats; n->prec = prec;
-        TG_HIP(ctx, hipMalloc((void**)&n->blob, sizeof(float) * n_floats));
         const size_t act = sizeof(float) * (size_t)rows_cap * P * F;
         TG_HIP(ctx, hipMalloc((void**)&n->bufA, act));
         TG_HIP(ctx, hipMalloc((void**)&n->bufB, act));
@@ -1240,41 +1318,28 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
         n->dma = (!any_att && (F == 128 || F == 256)) ? (getenv("TG_DMA_CONV") ? (atoi(getenv("TG_DMA_CONV")) != 0) : 1) : 0;
         if (prec == 1) n->dma = 0;
         const size_t wcopy = (size_t)(NB > 0 ? 2 * NB : 1) * 9 * F * F;
-        if (n->dma) TG_HIP(ctx, hipMalloc((void**)&n->wstage, sizeof(float) * wcopy));
         if (n->dma) TG_HIP(ctx, hipMalloc((void**)&n->bufAct, act));
         if (n->dma) TG_HIP(ctx, hipMalloc((void**)&n->tile_ctr, sizeof(int) * (size_t)(NB > 0 ? 2 * NB : 1)));
+        for (Net::WeightSet& w : n->sets) {
+            TG_HIP(ctx, hipMalloc((void**)&w.blob, sizeof(float) * n_floats));
+            if (n->dma) TG_HIP(ctx, hipMalloc((void**)&w.wstage, sizeof(float) * wcopy));
+            if (prec == 1) {
+                TG_HIP(ctx, hipMalloc((void**)&w.wh, sizeof(_Float16) * wcopy));
+                TG_HIP(ctx, hipMalloc((void**)&w.stem_h, sizeof(_Float16) * 9 * (size_t)F * 64));
+                TG_HIP(ctx, hipMalloc((void**)&w.head_h, sizeof(_Float16) * 9 * 16 * (size_t)F));
+            }
+        }
         if (prec == 1) {
-            TG_HIP(ctx, hipMalloc((void**)&n->wh, sizeof(_Float16) * wcopy));
             TG_HIP(ctx, hipMalloc((void**)&n->act16, act / 2));
             TG_HIP(ctx, hipMalloc((void**)&n->h16, act / 2));
-            TG_HIP(ctx, hipMalloc((void**)&n->stem_h, sizeof(_Float16) * 9 * (size_t)F * 64));
-            TG_HIP(ctx, hipMalloc((void**)&n->head_h, sizeof(_Float16) * 9 * 16 * (size_t)F));
             TG_HIP(ctx, hipMalloc((void**)&n->x0h, sizeof(_Float16) * (size_t)rows_cap * P * 64));
         }
-        const float* p = n->blob;
-        auto take = [&](size_t k) { const float* q = p; p += k; return q; };
-        auto take_att = [&](AttW& a) { a.qkv.w = take(Wq * F); a.qkv.b = take(Wq); a.gamma = take(1); a.s = take(F); a.t = take(F); };
-        n->stem.w = take(9 * (size_t)F * 16); n->stem.b = take(F);
-        n->blocks.resize(NB);
-        int ri = 0;
-        for (char c : trunk) {
-            Layer L; L.kind = c == 'A'; L.ridx = -1; L.a = AttW{};
-            if (c == 'R') {
-                BlockW& b = n->blocks[ri]; L.ridx = ri++;
-                b.s1 = take(F); b.t1 = take(F);
-                b.c1.w = take(9 * (size_t)F * F); b.c1.b = take(F);
-                b.c2.w = take(9 * (size_t)F * F); b.c2.b = take(F);
-                b.g1 = b.g2 = nullptr; b.h1 = b.h2 = nullptr;
-            } else {
-                take_att(L.a);
-            }
-            n->layers.push_back(L);
-        }
-        n->s_end = take(F); n->t_end = take(F);
-        if (pol) { take_att(n->patt); n->head_a.w = take(9 * 16 * (size_t)F); n->head_a.b = take(16); }
-        n->head.w = take(9 * 16 * (size_t)F); n->head.b = take(16);
-        n->w_vo = take(2 * P * 64); n->b_vo = take(64); n->w_v = take(64); n->b_v = take(1);
-        n->w_o = take(64 * P); n->b_o = take(P); n->w_a = take(4 * P * A); n->b_a = take(A);
+        TG_HIP(ctx, hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking));
+        TG_HIP(ctx, hipEventCreateWithFlags(&n->loaded, hipEventDisableTiming));
+        TG_HIP(ctx, hipEventCreateWithFlags(&n->swapped, hipEventDisableTiming));
+        TG_HIP(ctx, hipEventRecord(n->swapped, ctx->stream));
+        TG_HIP(ctx, hipHostMalloc((void**)&n->pinned, sizeof(float) * n_floats, hipHostMallocDefault));
+        n->active = 1;                                    // the load below fills set 0 and makes it the live one
         if (any_att) {
             const size_t lds = sizeof(float) * (P * Wq + P * (P + 1));
             if (lds <= 160 * 1024) {
@@ -1286,41 +1351,56 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
             }
         }
     }
-    // weight refresh (trainer.py:76-79 -> self_play.py:913) is just this copy
-    TG_HIP(ctx, hipMemcpyAsync(n->blob, blob, sizeof(float) * n_floats, hipMemcpyHostToDevice, ctx->stream));
-    const size_t per = 9 * (size_t)F * F;
-    if (n->prec == 1) {
-        // stage-ordered fp16 copies, converted on the device from the blob just uploaded (round to nearest even)
-        for (size_t i = 0; i < n->blocks.size(); ++i) {
-            BlockW& b = n->blocks[i];
-            _Float16* d1 = n->wh + (2 * i) * per; _Float16* d2 = n->wh + (2 * i + 1) * per;
-            hipLaunchKernelGGL(k_restage_half, dim3(1024), dim3(256), 0, ctx->stream, b.c1.w, d1, F, F, F, 32);     // k_conv3x3_h2: 32-channel stages
-            hipLaunchKernelGGL(k_restage_half, dim3(1024), dim3(256), 0, ctx->stream, b.c2.w, d2, F, F, F, 32);
-            b.h1 = d1; b.h2 = d2;
-        }
-        hipLaunchKernelGGL(k_restage_half, dim3(256), dim3(256), 0, ctx->stream, n->stem.w, n->stem_h, F, 16, 64, 32);
-        hipLaunchKernelGGL(k_restage_half, dim3(256), dim3(256), 0, ctx->stream, n->head.w, n->head_h, 16, F, F, 32);
-        TG_HIP(ctx, hipGetLastError());
-    } else if (n->dma) {
-        // stage-ordered copy for k_conv3x3_sg, [slice*9 + tap][cout][16 channels of the slice], made on the device
-        for (size_t i = 0; i < n->blocks.size(); ++i) {
-            BlockW& b = n->blocks[i];
-            float* d1 = n->wstage + (2 * i) * per; float* d2 = n->wstage + (2 * i + 1) * per;
-            hipLaunchKernelGGL(k_restage_f32, dim3(1024), dim3(256), 0, ctx->stream, b.c1.w, d1, F);
-            hipLaunchKernelGGL(k_restage_f32, dim3(1024), dim3(256), 0, ctx->stream, b.c2.w, d2, F);
-            b.g1 = d1; b.g2 = d2;
-        }
-        TG_HIP(ctx, hipGetLastError());
-    }
+    // Synchronous refresh (trainer.py:76-79 -> self_play.py:913): an asynchronous one still in flight is adopted first, then the
+    // retired set is filled on the context's own stream (in order behind every kernel that reads it) and becomes the live set.
+    { int rc = adopt_pending(ctx, n, /*wait=*/true); if (rc) return rc; }
+    const int k = n->active ^ 1;
+    { int rc = fill_weight_set(ctx, n, k, blob, ctx->stream); if (rc) return rc; }
     TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    n->active = k;
+    bind_weights(n, k);
     return TG_OK;
+}
+
+// The refresh that never stalls a search: the blob is copied to pinned memory, uploaded and re-staged into the
+// retired weight set on a side stream while the context's stream keeps searching on the live set; the first forward pass that
+// finds the upload complete switches over.  Needs a network already loaded with the same architecture (else: synchronous).
+int tg_net_load_async(tg_ctx* ctx, const char* arch_c, const float* blob, size_t n_floats) {
+    if (!ctx || !blob || !arch_c) return TG_ERR_ARG;
+    Net* n = ctx->eng ? ctx->eng->net : nullptr;
+    if (!n || n->arch != arch_c || n->blob_floats != n_floats || n->prec != ctx->cfg.net_precision)
+        return tg_net_load_arch(ctx, arch_c, blob, n_floats, 0);
+    TG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    { int rc = adopt_pending(ctx, n, /*wait=*/true); if (rc) return rc; }     // at most one refresh in flight
+    memcpy(n->pinned, blob, sizeof(float) * n_floats);
+    TG_HIP(ctx, hipStreamWaitEvent(n->side, n->swapped, 0));                 // nothing queued before the last switch reads this set now
+    { int rc = fill_weight_set(ctx, n, n->active ^ 1, n->pinned, n->side); if (rc) return rc; }
+    TG_HIP(ctx, hipEventRecord(n->loaded, n->side));
+    n->pending = true;
+    return TG_OK;
+}
+
+// pending = 1 while an asynchronous refresh has not been adopted yet; wait != 0 blocks until it is (and adopts it).
+int tg_net_load_poll(tg_ctx* ctx, int wait, int* pending) {
+    if (!ctx || !ctx->eng || !ctx->eng->net) return TG_ERR_STATE;
+    Net* n = ctx->eng->net;
+    TG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    int rc = adopt_pending(ctx, n, wait != 0);
+    if (pending) *pending = n->pending ? 1 : 0;
+    return rc;
 }
 
 void tg_net_destroy(tg_ctx* ctx) {
     if (!ctx || !ctx->eng || !ctx->eng->net) return;
     Net* n = ctx->eng->net;
-    void* ptrs[] = {n->blob, n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->bufQ, n->hca, n->bufAct, n->wstage, n->wh, n->act16, n->h16, n->stem_h, n->head_h, n->x0h, n->tile_ctr};
+    if (n->pending) (void)hipEventSynchronize(n->loaded);
+    void* ptrs[] = {n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->bufQ, n->hca, n->bufAct, n->act16, n->h16, n->x0h, n->tile_ctr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (Net::WeightSet& w : n->sets) { void* q[] = {w.blob, w.wstage, w.wh, w.stem_h, w.head_h}; for (void* p : q) if (p) (void)hipFree(p); }
+    if (n->side) (void)hipStreamDestroy(n->side);
+    if (n->loaded) (void)hipEventDestroy(n->loaded);
+    if (n->swapped) (void)hipEventDestroy(n->swapped);
+    if (n->pinned) (void)hipHostFree(n->pinned);
     for (hipEvent_t ev : n->ev) (void)hipEventDestroy(ev);
     delete n;
     ctx->eng->net = nullptr;

@@ -117,10 +117,15 @@ class BatchedSelfPlay:
             self.arch = _model.tower_arch(self.blocks)
         _model.load_into(self.engine.ctx, state_dict, self.S, self.config.encode_state_channels, self.filters, arch=self.arch)
 
-    def set_weights_blob(self, blob):
+    def set_weights_blob(self, blob, background=False):
+        """Packed blob -> GPU.  background=True: upload into the idle weight set on a side stream (tg_net_load_async) while
+        searches continue on the live one; the switch happens at the first network forward after the upload completed."""
         import ctypes
         blob = np.ascontiguousarray(blob, np.float32)
-        self.engine.ctx.call("tg_net_load_arch", self.arch.code.encode(), blob.ctypes.data_as(ctypes.c_void_p), blob.size, 0)
+        if background:
+            self.engine.ctx.call("tg_net_load_async", self.arch.code.encode(), blob.ctypes.data_as(ctypes.c_void_p), blob.size)
+        else:
+            self.engine.ctx.call("tg_net_load_arch", self.arch.code.encode(), blob.ctypes.data_as(ctypes.c_void_p), blob.size, 0)
 
     def _reset(self, mask=None):
         idx = range(self.G) if mask is None else np.flatnonzero(mask)
@@ -228,7 +233,7 @@ class SelfPlay:
         blob = self._fetch_blob(shared_storage_worker) if rank == 0 else None
         if not multi:
             if blob is not None:
-                wk.set_weights_blob(blob)
+                wk.set_weights_blob(blob, background=True)
             return
         import torch
         from .distributed import broadcast_weights
@@ -242,7 +247,7 @@ class SelfPlay:
                 wk.arch = _model.transgo_arch()
             n = _model._lib.load().tg_net_blob_floats_arch(wk.S, wk.config.encode_state_channels, wk.filters, wk.arch.code.encode())
             blob = np.zeros(n, np.float32)
-        wk.set_weights_blob(broadcast_weights(blob, src=0, device=dev))
+        wk.set_weights_blob(broadcast_weights(blob, src=0, device=dev), background=True)
 
     def policy_evaluate(self, n_games=10, shared_storage_worker=None, seed=0, evaluators=None):
         """New-vs-old evaluation matches (self_play.py:986-1040): the train model ("weights") against the evaluation model

@@ -82,13 +82,16 @@ def test_reference_mainnetwork_with_attention(golden_dir):
     assert ep < TOL and ev < TOL and eo < TOL
 
 
-def test_mainnetwork_default_width_vs_oracle():
-    """F=128 (the reference default, configure.py:37) against the torch restatement that the fixture above pins."""
+@pytest.mark.parametrize("F", [128, 256, 64])
+def test_mainnetwork_default_width_vs_oracle(F):
+    """F=128 (the reference default, configure.py:37) against the torch restatement that the fixture above pins; 128 and 256 run
+    the residual blocks on the DMA-fed k_conv3x3_sg chain and Self_Attention on the matrix cores (k_attention_mfma), 64 the
+    general kernels."""
     import torch
     from oracle.net import TransGoMain
     from transgo_amd.model import HipNetwork, transgo_arch
     torch.manual_seed(3); torch.set_num_threads(4)
-    net = TransGoMain(9, 10, 128).eval()
+    net = TransGoMain(9, 10, F).eval()
     g = torch.Generator().manual_seed(4)
     with torch.no_grad():
         for m in net.modules():
@@ -100,11 +103,11 @@ def test_mainnetwork_default_width_vs_oracle():
     x = _positions(9, 70, 11)
     with torch.no_grad():
         p, v, o = net.main_prediction(torch.from_numpy(x))
-    h = HipNetwork(9, 10, 128, rows_cap=64, arch=transgo_arch())
+    h = HipNetwork(9, 10, F, rows_cap=64, arch=transgo_arch())
     h.set_weights({k: t.numpy() for k, t in net.state_dict().items()})
     hp, hv, ho = h.main_prediction(x)
     ep, ev, eo = np.abs(hp - p.numpy()).max(), np.abs(hv - v.numpy()).max(), np.abs(ho - o.numpy()).max()
-    print(f"MainNetwork F=128: max abs err policy {ep:.2e} value {ev:.2e} own {eo:.2e}")
+    print(f"MainNetwork F={F}: max abs err policy {ep:.2e} value {ev:.2e} own {eo:.2e}")
     assert ep < TOL and ev < TOL and eo < TOL
 
 

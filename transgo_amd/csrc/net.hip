@@ -941,6 +941,157 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
     }
 }
 
+// The same Self_Attention core on the matrix cores (F = 64, 128, 256 at 9x9): ONE WAVE PER BOARD, everything between the q/k/v
+// projection and the block's output stays in registers.
+//   GEMM 1  energy[i][j] = sum_c q[i][c] k[j][c]        (P x P x F/4; 6 x 6 tiles of 16 x 16, P = 81 padded to 96)
+//   softmax over j, row by row, on the accumulator tiles themselves (a row lives in 16 lanes x 6 tiles: in-register max/sum
+//           + 4 xor-shuffles); padded columns are excluded, padded rows zeroed
+//   GEMM 2  out[c][j] = sum_i v[i][c] attention[i][j]   (F x P x P).  The D layout of a 16x16x4 MFMA tile (column = lane & 15,
+//           row = 4*(lane >> 4) + r) IS the B-operand layout with k = 4*(lane >> 4) + s, so the softmaxed tiles feed GEMM 2
+//           without leaving their registers; only v is loaded (each element once, 64-B runs).  i = 81 needs 21 k-steps, not 24.
+//   y = relu(bn(gamma * out + x)), written row-major (the residual stream) and, when the next layer is a residual block of the
+//   DMA-fed chain, also as its pre-activated slice-major input relu(bn1_next(y)) (out2).
+// MFMA work per board: 288 + 1008 instructions of 16x16x4 (F = 128) = 1.3 % of an F->F conv's; the scalar-FMA kernel above took
+// 8.3 ms per 16384 boards (3 x an F->F conv), this one is bounded by its 97 KB of q/k/v/x/y traffic per board.
+#ifndef TG_ATT_OCC
+#define TG_ATT_OCC 1
+#endif
+template <int S, int F, int CP>
+__global__ __launch_bounds__(256, TG_ATT_OCC) void k_attention_mfma(const float* __restrict__ qkv, const float* __restrict__ xin,
+                                                        float* __restrict__ out, float* __restrict__ out2,
+                                                        const float* __restrict__ gamma, const float* __restrict__ bs,
+                                                        const float* __restrict__ bt, const float* __restrict__ ps,
+                                                        const float* __restrict__ pt, const float* __restrict__ s2,
+                                                        const float* __restrict__ t2, int rows) {
+    constexpr int P = S * S, FQ = F / 4, W = 2 * FQ + F, NT = (P + 15) / 16, CT = F / 16, NSUB = FQ / 16;
+    static_assert(P <= 96 && FQ % 16 == 0 && CT % CP == 0, "attention tile geometry");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= rows) return;
+    const int j = lane & 15, kq = lane >> 4;
+    const float* base = qkv + (size_t)b * P * W;
+    const int M = rows * P;
+    // ---- GEMM 1 ----
+    f32x4 e[NT][NT];
+#pragma unroll
+    for (int tm = 0; tm < NT; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn) e[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+        // padded rows (>= P) repeat the last one; their columns / rows are masked below.  k fragments of the slice stay resident,
+        // q fragments stream through one register quad (one ahead), so the 36 energy tiles dominate the register budget
+        auto row_of = [&](int t) { return t * 16 + j < P ? t * 16 + j : P - 1; };
+        f32x4 kb[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) kb[t] = *reinterpret_cast<const f32x4*>(base + (size_t)row_of(t) * W + FQ + sub * 16 + kq * 4);
+        f32x4 qa = *reinterpret_cast<const f32x4*>(base + (size_t)row_of(0) * W + sub * 16 + kq * 4);
+#pragma unroll
+        for (int tm = 0; tm < NT; ++tm) {
+            f32x4 qn = qa;
+            if (tm + 1 < NT) qn = *reinterpret_cast<const f32x4*>(base + (size_t)row_of(tm + 1) * W + sub * 16 + kq * 4);
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+                    e[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s4], kb[tn][s4], e[tm][tn], 0, 0, 0);
+            qa = qn;
+        }
+    }
+    // ---- softmax over j (columns) for every row i = tm*16 + kq*4 + r ----
+#pragma unroll
+    for (int tm = 0; tm < NT; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn) if (tn * 16 + j < P) mx = e[tm][tn][r] > mx ? e[tm][tn][r] : mx;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { const float t = __shfl_xor(mx, o); mx = t > mx ? t : mx; }
+            float sum = 0.f;
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn) {
+                const float v = tn * 16 + j < P ? __expf(e[tm][tn][r] - mx) : 0.f;        // v_exp_f32: ~1e-7 relative, tolerance is 1e-3
+                e[tm][tn][r] = v; sum += v;
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
+            const float inv = (tm * 16 + kq * 4 + r < P) ? 1.f / sum : 0.f;     // rows past the board contribute nothing to GEMM 2
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn) e[tm][tn][r] *= inv;
+        }
+    }
+    // ---- GEMM 2 + epilogue, CP channel tiles per pass ----
+    // One wave per SIMD (the 36 energy tiles alone are 144 registers), so latency is hidden inside the wave: ALL v operands of a
+    // pass (NK k-steps x CP tiles, 4 B each) are requested while the previous pass computes -- with one step of lead the kernel
+    // sat on load latency (84 dependent round trips per board, 1.14 ms per 16384 boards).
+    const float g = gamma[0];
+    const float* vb = base + 2 * FQ;
+    constexpr int LASTS = P - (NT - 1) * 16, NS_LAST = LASTS < 4 ? LASTS : 4, NK = (NT - 1) * 4 + NS_LAST, NPASS = CT / CP;
+    // k-step kk covers rows i = (kk/4)*16 + kq*4 + kk%4; of the last 16-row block only the steps that touch a row < P exist
+    float av[2][NK][CP];
+    auto load_pass = [&](int pass, float (*dst)[CP]) {
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            const int i = (kk >> 2) * 16 + kq * 4 + (kk & 3);
+            const int ic = i < P ? i : P - 1;                                         // the matching attention rows are zero
+#pragma unroll
+            for (int cp = 0; cp < CP; ++cp) dst[kk][cp] = vb[(size_t)ic * W + (pass * CP + cp) * 16 + j];
+        }
+    };
+    load_pass(0, av[0]);
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int c0 = pass * CP;
+        if (pass + 1 < NPASS) load_pass(pass + 1, av[(pass + 1) & 1]);
+        f32x4 acc[CP][NT];
+#pragma unroll
+        for (int cp = 0; cp < CP; ++cp)
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn) acc[cp][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+            for (int cp = 0; cp < CP; ++cp)
+#pragma unroll
+                for (int tn = 0; tn < NT; ++tn)
+                    acc[cp][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[pass & 1][kk][cp], e[kk >> 2][tn][kk & 3], acc[cp][tn], 0, 0, 0);
+        // D tile: row = channel (c0+cp)*16 + kq*4 + r, column = position tn*16 + j
+#pragma unroll
+        for (int cp = 0; cp < CP; ++cp) {
+            const int c = (c0 + cp) * 16 + kq * 4;
+            const f32x4 vbs = *reinterpret_cast<const f32x4*>(bs + c), vbt = *reinterpret_cast<const f32x4*>(bt + c);
+            f32x4 vps = f32x4{1.f, 1.f, 1.f, 1.f}, vpt = f32x4{0.f, 0.f, 0.f, 0.f}, vs2 = vps, vt2 = vpt;
+            if (ps) { vps = *reinterpret_cast<const f32x4*>(ps + c); vpt = *reinterpret_cast<const f32x4*>(pt + c); }
+            if (out2) { vs2 = *reinterpret_cast<const f32x4*>(s2 + c); vt2 = *reinterpret_cast<const f32x4*>(t2 + c); }
+            f32x4 x[NT];
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn) {
+                const int p = tn * 16 + j < P ? tn * 16 + j : P - 1;
+                x[tn] = *reinterpret_cast<const f32x4*>(xin + (size_t)(b * P + p) * F + c);
+            }
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn) {
+                const int p = tn * 16 + j;
+                if (p >= P) continue;
+                const int m = b * P + p;
+                f32x4 y, u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float xv = x[tn][q];
+                    if (ps) { xv = xv * vps[q] + vpt[q]; xv = xv > 0.f ? xv : 0.f; }
+                    const float w = (g * acc[cp][tn][q] + xv) * vbs[q] + vbt[q];
+                    y[q] = w > 0.f ? w : 0.f;
+                    const float z = y[q] * vs2[q] + vt2[q];
+                    u[q] = z > 0.f ? z : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(out + (size_t)m * F + c) = y;
+                if (out2) *reinterpret_cast<f32x4*>(out2 + f32_sm_index(m, c, M)) = u;
+            }
+        }
+    }
+}
+
 // Heads after the 3x3 head convs (hc[row][p][16]: channels 0-1 value/own, 2-5 policy; BN+ReLU already applied).
 template <int S>
 __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ hc, const float* __restrict__ hca, const float* __restrict__ w_vo,
@@ -1059,22 +1210,50 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
             return TG_OK;
         }
         if (n->dma && (long long)M * F * 4 < (1ll << 31)) {
-            // prologue-free chain: every producer also writes relu(bn_next(.)) for its consumer
-            const size_t nb = n->blocks.size();
-            const float* s0 = nb ? n->blocks[0].s1 : n->s_end; const float* t0 = nb ? n->blocks[0].t1 : n->t_end;
-            if (nb) (void)hipMemsetAsync(n->tile_ctr, 0, sizeof(int) * 2 * nb, st);     // dynamic tile counters of the conv launches
+            // Prologue-free chain over the layer program: every producer (stem, the second conv of a residual block, an attention
+            // block) also writes relu(bn1_next(.)) slice-major for a residual block that follows, so the DMA-fed F->F kernels never
+            // activate anything.  Attention layers read and write the row-major residual stream (the reference's shipped
+            // MainNetwork, "RARRRARRRRAR+P", runs its nine residual blocks on k_conv3x3_sg this way).
+            const size_t nl = n->layers.size();
+            auto next_bn = [&](size_t i, const float** sn, const float** tn) -> bool {   // layer i+1 is a residual block?
+                if (i + 1 < nl && n->layers[i + 1].kind == 0) { const BlockW& nb2 = n->blocks[n->layers[i + 1].ridx]; *sn = nb2.s1; *tn = nb2.t1; return true; }
+                *sn = nullptr; *tn = nullptr; return false;
+            };
+            const float* s0 = nullptr; const float* t0 = nullptr;
+            const bool act0 = nl && n->layers[0].kind == 0;
+            if (act0) { s0 = n->blocks[n->layers[0].ridx].s1; t0 = n->blocks[n->layers[0].ridx].t1; }
+            if (n->NB) (void)hipMemsetAsync(n->tile_ctr, 0, sizeof(int) * 2 * n->NB, st);     // dynamic tile counters of the conv launches
             hipLaunchKernelGGL((k_conv3x3<S, 16, F, false, 0, 9, 2, true>), dim3(grid), dim3(256), 0, st, (const float*)n->x0, x,
                                (const float*)nullptr, n->stem.w, n->stem.b, (const float*)nullptr, (const float*)nullptr, M,
-                               nb ? n->bufAct : (float*)nullptr, s0, t0);
-            for (size_t i = 0; i < nb; ++i) {
-                const BlockW& b = n->blocks[i];
-                const float* sn = i + 1 < nb ? n->blocks[i + 1].s1 : n->s_end;
-                const float* tn = i + 1 < nb ? n->blocks[i + 1].t1 : n->t_end;
+                               act0 ? n->bufAct : (float*)nullptr, s0, t0);
+            constexpr int WQ = F / 4 + F / 4 + F;
+            auto attention_fast = [&](const AttW& a, const float* xin, float* xout, const float* ps, const float* pt, float* o2,
+                                      const float* sn, const float* tn) {
+                if (ps)
+                    hipLaunchKernelGGL((k_conv3x3<S, F, WQ, true, 2, 1>), dim3(grid), dim3(256), 0, st, xin, n->bufQ,
+                                       (const float*)nullptr, a.qkv.w, a.qkv.b, ps, pt, M);
+                else
+                    hipLaunchKernelGGL((k_conv3x3<S, F, WQ, false, 2, 1>), dim3(grid), dim3(256), 0, st, xin, n->bufQ,
+                                       (const float*)nullptr, a.qkv.w, a.qkv.b, (const float*)nullptr, (const float*)nullptr, M);
+                if constexpr (S == 9)
+                    hipLaunchKernelGGL((k_attention_mfma<S, F, 2>), dim3((rows + 3) / 4), dim3(256), 0, st, (const float*)n->bufQ, xin, xout,
+                                       o2, a.gamma, a.s, a.t, ps, pt, sn, tn, rows);
+            };
+            for (size_t i = 0; i < nl; ++i) {
+                const Layer& L = n->layers[i];
+                const float* sn; const float* tn;
+                const bool act = next_bn(i, &sn, &tn);
+                if (L.kind == 1) {
+                    attention_fast(L.a, x, y, nullptr, nullptr, act ? n->bufAct : (float*)nullptr, sn, tn);
+                    float* t = x; x = y; y = t;
+                    continue;
+                }
+                const BlockW& b = n->blocks[L.ridx];
                 constexpr int SD_TM = F == 128 ? 192 : 128;
                 const int ntile_sd = (M + SD_TM - 1) / SD_TM, slots_sd = F == 128 ? ntile_sd : 512;  // F=256: 2 resident workgroups x 256 CUs walk a dynamic tile list
                 const int grid_sd = ntile_sd < slots_sd ? ntile_sd : slots_sd;
-                int* const ctr1 = n->tile_ctr + 2 * i; int* const ctr2 = ctr1 + 1;                  // zeroed at the top of the forward
-                float* const actn = i + 1 < nb ? n->bufAct : (float*)nullptr;
+                int* const ctr1 = n->tile_ctr + 2 * L.ridx; int* const ctr2 = ctr1 + 1;              // zeroed at the top of the forward
+                float* const actn = act ? n->bufAct : (float*)nullptr;
                 { ProfScope ps(n, st, conv_flops);
                   hipLaunchKernelGGL((k_conv3x3_sg<S, F, 0>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufAct, n->bufH,
                                      (const float*)nullptr, b.g1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, ctr1); }
@@ -1083,10 +1262,17 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                                      (const float*)x, b.g2, b.c2.b, actn, sn, tn, M, ctr2); }
                 float* t = x; x = y; y = t;
             }
-            // bufAct / bufH are slice-major; the head conv reads the row-major residual stream and activates it while staging
+            // bufAct / bufH are slice-major; the head convs read the row-major residual stream and activate it while staging
             hipLaunchKernelGGL((k_conv3x3<S, F, 16, true, 0>), dim3(grid), dim3(256), 0, st, (const float*)x, n->hc,
                                (const float*)nullptr, n->head.w, n->head.b, n->s_end, n->t_end, M);
-            hipLaunchKernelGGL((k_heads<S>), dim3(rows), dim3(256), 0, st, (const float*)n->hc, (const float*)n->hc, n->w_vo, n->b_vo,
+            const float* hca = n->hc;
+            if (n->pol_att) {                              // attention in the policy head (model.py:72,106-107) on relu(bn_end(x))
+                attention_fast(n->patt, x, y, n->s_end, n->t_end, (float*)nullptr, (const float*)nullptr, (const float*)nullptr);
+                hipLaunchKernelGGL((k_conv3x3<S, F, 16, false, 0>), dim3(grid), dim3(256), 0, st, (const float*)y, n->hca,
+                                   (const float*)nullptr, n->head_a.w, n->head_a.b, (const float*)nullptr, (const float*)nullptr, M);
+                hca = n->hca;
+            }
+            hipLaunchKernelGGL((k_heads<S>), dim3(rows), dim3(256), 0, st, (const float*)n->hc, hca, n->w_vo, n->b_vo,
                                n->w_v, n->b_v, n->w_o, n->b_o, n->w_a, n->b_a, policy, value, own);
             TG_HIP(ctx, hipGetLastError());
             return TG_OK;
@@ -1315,7 +1501,8 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
 
         if (any_att) TG_HIP(ctx, hipMalloc((void**)&n->bufQ, sizeof(float) * (size_t)rows_cap * P * Wq));
         if (pol) TG_HIP(ctx, hipMalloc((void**)&n->hca, sizeof(float) * (size_t)rows_cap * P * 16));
-        n->dma = (!any_att && (F == 128 || F == 256)) ? (getenv("TG_DMA_CONV") ? (atoi(getenv("TG_DMA_CONV")) != 0) : 1) : 0;
+        // DMA-fed F->F chain: f32 towers of 128 / 256 filters, with or without attention layers (those need the 9x9 MFMA kernel)
+        n->dma = ((F == 128 || F == 256) && (!any_att || S == 9)) ? (getenv("TG_DMA_CONV") ? (atoi(getenv("TG_DMA_CONV")) != 0) : 1) : 0;
         if (prec == 1) n->dma = 0;
         const size_t wcopy = (size_t)(NB > 0 ? 2 * NB : 1) * 9 * F * F;
         if (n->dma) TG_HIP(ctx, hipMalloc((void**)&n->bufAct, act));

@@ -220,3 +220,51 @@ def random_weights(board_size=9, encode_dim=10, filters=128, blocks=6, seed=1234
     conv(p + "conv_act.conv.0", F, 4); bn(p + "conv_act.conv.1", 4)
     lin(p + "fc_act", 4 * P, A)
     return sd
+
+
+def random_transgo_weights(board_size=9, encode_dim=10, filters=128, seed=1234):
+    """Synthetic random-init state_dict of the reference's shipped MainNetwork (model.py:41-114: res_conv2..res_conv13 with
+    Self_Attention at 3, 7, 12, attention policy head), same distributions as random_weights; gamma ~ U(0.5, 1.5) so the
+    attention branch is live (the reference initialises gamma to 0, which would make every attention block a no-op)."""
+    rs = np.random.RandomState(seed)
+    S, C, F = board_size, encode_dim, filters
+    P, A = S * S, S * S + 1
+    sd = {}
+
+    def conv(name, cin, cout, k=3):
+        b = 1.0 / np.sqrt(cin * k * k)
+        sd[name + ".weight"] = rs.uniform(-b, b, (cout, cin, k, k)).astype(np.float32)
+        sd[name + ".bias"] = rs.uniform(-b, b, (cout,)).astype(np.float32)
+
+    def lin(name, cin, cout):
+        b = 1.0 / np.sqrt(cin)
+        sd[name + ".weight"] = rs.uniform(-b, b, (cout, cin)).astype(np.float32)
+        sd[name + ".bias"] = rs.uniform(-b, b, (cout,)).astype(np.float32)
+
+    def bn(name, c):
+        sd[name + ".weight"] = (1.0 + 0.1 * rs.randn(c)).astype(np.float32)
+        sd[name + ".bias"] = (0.1 * rs.randn(c)).astype(np.float32)
+        sd[name + ".running_mean"] = (0.1 * rs.randn(c)).astype(np.float32)
+        sd[name + ".running_var"] = rs.uniform(0.5, 1.5, c).astype(np.float32)
+        sd[name + ".num_batches_tracked"] = np.int64(0)
+
+    def att(name):
+        conv(name + ".query_conv", F, F // 4, 1); conv(name + ".key_conv", F, F // 4, 1); conv(name + ".value_conv", F, F, 1)
+        sd[name + ".gamma"] = rs.uniform(0.5, 1.5, 1).astype(np.float32)
+        bn(name + ".bn", F)
+
+    p = "main_network."
+    conv(p + "conv1.conv.0", C, F); bn(p + "conv1.conv.1", F)
+    for i in range(2, 14):
+        q = p + f"res_conv{i}"
+        if i in (3, 7, 12):
+            att(q)
+        else:
+            bn(q + ".batchnormlize_1", F); conv(q + ".conv_1", F, F); bn(q + ".batchnormlize_2", F); conv(q + ".conv_2", F, F)
+    bn(p + "bn_res_end", F)
+    conv(p + "conv_val_own.conv.0", F, 2); bn(p + "conv_val_own.conv.1", 2)
+    lin(p + "fc_val_own", 2 * P, 64); lin(p + "fc_val", 64, 1); lin(p + "fc_own", 64, P)
+    att(p + "attention_act")
+    conv(p + "conv_act.conv.0", F, 4); bn(p + "conv_act.conv.1", 4)
+    lin(p + "fc_act", 4 * P, A)
+    return sd

@@ -93,7 +93,7 @@ def test_get_sub_encode_equals_the_compiled_reference():
 def test_missing_library_fails_loudly(tmp_path):
     """No CPU fallback: with the shared library absent the package raises at first use instead of computing anything."""
     import subprocess, sys
-    code = ("import os, sys; os.environ['TG_LIB'] = sys.argv[1]; from transgo_amd import _lib\n"
+    code = ("import sys; from transgo_amd import _lib; _lib.LIB_PATH = sys.argv[1]\n"
             "try:\n    _lib.load()\nexcept _lib.TransgoError as e:\n    print('RAISED', 'not found' in str(e))\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code, str(tmp_path / "nope.so")], capture_output=True, text=True, cwd=root, timeout=120)

@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("TG_LIB") or os.path.join(_HERE, "libtransgo_hip.so")   # TG_LIB: A/B builds during kernel tuning
+LIB_PATH = os.path.join(_HERE, "libtransgo_hip.so")     # the in-tree build only: no environment override of the product library
 
 
 class TgConfig(ctypes.Structure):

@@ -323,20 +323,6 @@ __device__ __forceinline__ void tg_dma_buffer(u32x4 rsrc, int voff_bytes, tg_lds
 // conflicted on every read (measured: SQ_LDS_BANK_CONFLICT = 49 % of SQ_LDS_IDX_ACTIVE).
 __device__ __forceinline__ int swz64(int row) { return ((row >> 2) & 1) << 1; }
 
-#ifdef TG_SD_STAMP
-__device__ unsigned long long tg_sd_dbg[8];          // diagnostic build only: summed cycles per phase, all waves
-#define TG_STAMP(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory")
-#endif
-#ifndef TG_H_DA
-#define TG_H_DA 4
-#endif
-#ifdef TG_H_NT
-#define TG_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
-#define TG_NT_LOAD(p) __builtin_nontemporal_load(p)
-#else
-#define TG_NT_STORE(v, p) (*(p) = (v))          // measured: nontemporal stores/loads here are 7 % SLOWER (0.88 vs 0.82 ms per launch)
-#define TG_NT_LOAD(p) (*(p))
-#endif
 #ifndef TG_SG_NG
 #define TG_SG_NG 2           // k_conv3x3_sg at F=128: stages per barrier (ring = 2*NG slots of 8 KB); measured 2: 138.5, 3: 131.6, 4: 127.1 TFLOP/s
 #endif
@@ -504,7 +490,7 @@ __device__ __forceinline__ void conv_epilogue_h(f32x4 (&acc)[CT][NPT], const int
         if (mrow[t] < M) {
 #pragma unroll
             for (int i = 0; i < CH; ++i)
-                dst[i] = TG_NT_LOAD(reinterpret_cast<const f32x4*>(res + (size_t)mrow[t] * F + co_base + (h * CH + i) * 16 + kq * 4));
+                dst[i] = *(reinterpret_cast<const f32x4*>(res + (size_t)mrow[t] * F + co_base + (h * CH + i) * 16 + kq * 4));
         }
     };
     if (EPI == 1) load_res(0, r[0]);
@@ -521,20 +507,20 @@ __device__ __forceinline__ void conv_epilogue_h(f32x4 (&acc)[CT][NPT], const int
                 if (EPI == 0) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) u[e] = (_Float16)(v[e] > 0.f ? v[e] : 0.f);
-                    TG_NT_STORE(u, reinterpret_cast<h4*>(out16 + h16_index(mrow[t], col, M)));
+                    *reinterpret_cast<h4*>(out16 + h16_index(mrow[t], col, M)) = u;
                 } else {
                     if (EPI == 1) v = v + r[c & 1][i];
                     if (EPI == 4) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                     }
-                    if (out32) TG_NT_STORE(v, reinterpret_cast<f32x4*>(out32 + (size_t)mrow[t] * F + col));   // null: the last block (only its activation feeds the head)
+                    if (out32) *reinterpret_cast<f32x4*>(out32 + (size_t)mrow[t] * F + col) = v;   // null: the last block (only its activation feeds the head)
                     if (out16) {
                         const f32x4 sc = *reinterpret_cast<const f32x4*>(par + pstride + lc);
                         const f32x4 sh = *reinterpret_cast<const f32x4*>(par + 2 * pstride + lc);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { const float w = v[e] * sc[e] + sh[e]; u[e] = (_Float16)(w > 0.f ? w : 0.f); }
-                        TG_NT_STORE(u, reinterpret_cast<h4*>(out16 + h16_index(mrow[t], col, M)));
+                        *reinterpret_cast<h4*>(out16 + h16_index(mrow[t], col, M)) = u;
                     }
                 }
             }
@@ -661,10 +647,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
                 if (EPI == 1 && m < M) acc[ct][t] = *reinterpret_cast<const f32x4*>(res + (size_t)m * F + co0 + ct * 16 + kq * 4);
             }
         }
-#ifdef TG_SD_STAMP
-        unsigned long long t_start, t_pro, t_0, t_a, t_b, t_c, t_loop, t_end, s_dma = 0, s_bar = 0, s_iss = 0, s_cmp = 0;
-        TG_STAMP(t_start);
-#endif
         // first tile of a residual-free launch: only the prologue DMAs are in flight, so the wait can leave X(1), W(2), W(3) out;
         // otherwise residual loads / the previous tile's stores are younger than them and everything is waited for
         if (EPI != 1 && first && NSL > 1) vmcnt_uniform<NXQ + 2 * WPW>((NXP - wave * NXQ < 0 ? 0 : NXP - wave * NXQ > NXQ ? NXQ : NXP - wave * NXQ) + 2 * WPW);
@@ -673,19 +655,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
         first = false;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         TG_BARRIER();
-#ifdef TG_SD_STAMP
-        TG_STAMP(t_pro);
-#endif
         f32x4 b_cur[NPT], b_next[NPT];
         read_b(b_cur, 0);
 
 #pragma unroll 1                                                         // unrolled, hipcc keeps 4 pairs of address state live and spills
         for (int pp = 0; pp < NPAIR; ++pp) {
-            constexpr int NU = 2 * CT, DA = TG_H_DA;
+            constexpr int NU = 2 * CT, DA = 4;
             const int g0 = 2 * pp;
-#ifdef TG_SD_STAMP
-            TG_STAMP(t_0);
-#endif
             // A fragments run DA-1 steps ahead of their MFMAs (a step = 4 MFMAs = 64 cycles; an LDS read under load takes longer)
             f32x4 a[DA];
 #pragma unroll
@@ -709,18 +685,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
             }
             // every DMA of this wave was issued at least one pair ago: wait for all of them, then meet the other waves.  After the
             // barrier the two slots of this pair are free, and so is the slab buffer of slice sl-1 once stage 9*sl-1 is behind us.
-#ifdef TG_SD_STAMP
-            TG_STAMP(t_a);
-#endif
             TG_VMCNT(0);
-#ifdef TG_SD_STAMP
-            TG_STAMP(t_b);
-#endif
             TG_BARRIER();
-#ifdef TG_SD_STAMP
-            TG_STAMP(t_c);
-            s_cmp += t_a - t_0; s_dma += t_b - t_a; s_bar += t_c - t_b;
-#endif
             const int gdone = g0 + 1;                                    // last finished stage
             // the slab of slice sl+1 goes into the buffer slice sl-1 used: issue it right after the pair that finished stage 9*sl-1
             // (it is fenced by the NEXT pair's barrier, i.e. before stage 9*sl+3; first read by the prefetch in stage 9*sl+8)
@@ -729,13 +695,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
                 if (sl >= 1 && sl + 1 < NSL && (gdone == 9 * sl - 1 || gdone == 9 * sl)) dma_x(sl + 1);
             }
             if (g0 + 4 < NST) { dma_w(g0 + 4); dma_w(g0 + 5); }
-#ifdef TG_SD_STAMP
-            TG_STAMP(t_0); s_iss += t_0 - t_c;
-#endif
         }
-#ifdef TG_SD_STAMP
-        TG_STAMP(t_loop);
-#endif
         int mrow[NPT];
 #pragma unroll
         for (int t = 0; t < NPT; ++t) mrow[t] = m0 + (wave * NPT + t) * 16 + j;
@@ -746,14 +706,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
         const bool have_next = nb < nblk;
         if (have_next) { bid = nb; m0 = tile_m0(nb); prologue(); }
         conv_epilogue_h<F, CT, NPT, (EPI == 1 ? 2 : EPI)>(acc, mrow, M, co0, kq, out32, out16, res, par, NCO);   // EPI 4: the stem
-#ifdef TG_SD_STAMP
-        TG_STAMP(t_end);
-        if (lane == 0) {
-            atomicAdd(&tg_sd_dbg[0], t_pro - t_start); atomicAdd(&tg_sd_dbg[1], s_dma); atomicAdd(&tg_sd_dbg[2], s_bar);
-            atomicAdd(&tg_sd_dbg[3], t_loop - t_pro); atomicAdd(&tg_sd_dbg[4], t_end - t_loop); atomicAdd(&tg_sd_dbg[5], 1ull);
-            atomicAdd(&tg_sd_dbg[6], s_iss); atomicAdd(&tg_sd_dbg[7], s_cmp);
-        }
-#endif
         if (!have_next) break;
     }
 }
@@ -1624,14 +1576,6 @@ int tg_net_predict(tg_ctx* ctx, const float* obs, int n_rows, float* policy, flo
     return TG_OK;
 }
 
-#ifdef TG_SD_STAMP
-int tg_dbg_read(unsigned long long* out8) {
-    unsigned long long z[8] = {0};
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(tg_sd_dbg), sizeof(z)) != hipSuccess) return -1;
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(tg_sd_dbg), z, sizeof(z));
-    return 0;
-}
-#endif
 
 // HIP-event timing of the dominant kernel (3x3 conv F->F), measured on the stream the kernels are launched on.
 int tg_prof_enable(tg_ctx* ctx, int on, int max_launches) {

@@ -240,6 +240,7 @@ def main():
     eng.ctx.call("tg_prof_read_tree", None, None, None, ctypes.byref(cs0))
     st0 = eng.stats()
     fin0, drop0 = sp.games_finished, sp.games_dropped
+    sp.phase_s = {}; eng.begin_move_s = 0.0
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -265,7 +266,7 @@ def main():
         # HBM bytes per launch of the dominant kernel come from PMC passes (separate rocprofv3 runs, committed under profiles/);
         # they only describe the configuration they were collected on
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json" if a.dtype == "f32" else "r1_pmc_traffic_f16.json")
+        tfile = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json" if a.dtype == "f32" else "r1_pmc_traffic_f16.json")
         if os.path.exists(tfile) and (S, a.filters, a.games, a.network) == (9, 128, 4096, "tower"):
             with open(tfile) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch_mean")
@@ -311,7 +312,13 @@ def main():
                                "replay_entries": info["entries"], "consumer": "DeviceReplayMemory on rank 0 (tg_replay_append_dev)"},
             "extra": {"leaves_per_s": round(evals_all / dt, 1), "mean_depth": round(depth_all / max(1.0, sims_all), 3),
                       "net_tflops_end_to_end": round(evals_all * fpl / dt / 1e12, 2) if fpl else None,
-                      "tree_errors": st1["errors"], "arena_high_water_slots": st1["max_slots"]},
+                      "tree_errors": st1["errors"], "arena_high_water_slots": st1["max_slots"],
+                      "truncated_tree_blocks": st1["truncated_blocks"],
+                      "step_phases_ms": dict({k: round(v / a.steps * 1e3, 2) for k, v in sp.phase_s.items()},
+                                             begin_move_inside_search=round(eng.begin_move_s / a.steps * 1e3, 2)),
+                      "step_phases_note": "rank 0 wall clock per step: search = root noise (host Dirichlet) + all waves; select = visit "
+                                          "counts D2H + pi/move sampling on the host; play = record + re-root kernel + new-root evaluation; "
+                                          "game_end = harvest + restart of finished slots (gather/append are outside these four)"},
         }
         print(json.dumps(line))
     if world > 1:

@@ -8,6 +8,7 @@ bit-identical by construction.  The random numbers for it come from the game's o
 """
 import ctypes
 import math
+import time
 
 import numpy as np
 
@@ -82,6 +83,7 @@ class SelfPlayEngine:
         self.finished = np.zeros(n_games, bool)      # slots that take no part in the next search (game over, parked, in error)
         self.errored = np.zeros(n_games, bool)       # slots parked by a tree-arena overflow (restart them with reset(mask))
         self.device = device
+        self.begin_move_s = 0.0                      # wall clock spent in tg_sp_begin_move (root noise on the host), for bench.py
 
     def close(self):
         self.ctx.close()
@@ -144,7 +146,9 @@ class SelfPlayEngine:
 
     def search(self, selfplay=True, num_simulation=0):
         """The search part of get_action_probs (self_play.py:659-664)."""
+        t0 = time.perf_counter()
         self.ctx.call("tg_sp_begin_move", 1 if selfplay else 0, num_simulation)
+        self.begin_move_s += time.perf_counter() - t0
         if self.evaluator is None:
             w = ctypes.c_int32()
             self.ctx.call("tg_sp_search", ctypes.byref(w))

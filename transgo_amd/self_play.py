@@ -100,6 +100,7 @@ class BatchedSelfPlay:
         self.moves_played = 0
         self.games_finished = 0
         self.games_dropped = 0                             # games abandoned because their tree outgrew the arena
+        self.phase_s = {}
         self._started = False
 
     def seed_of(self, g):
@@ -146,10 +147,14 @@ class BatchedSelfPlay:
             self.start()
         eng = self.engine
         live = int((~eng.finished).sum())
+        t0 = time.perf_counter()
         eng.search(selfplay, num_simulation)
+        t1 = time.perf_counter()
         vis, steps = eng.root_visits()
         actions, _ = eng.choose_moves(vis, steps, selfplay)
+        t2 = time.perf_counter()
         done = eng.play(actions)
+        t3 = time.perf_counter()
         self.moves_played += live
         h = None
         if done.any():
@@ -159,6 +164,9 @@ class BatchedSelfPlay:
         if restart.any():
             self.games_dropped += int(eng.errored.sum())
             self._reset(restart)
+        t4 = time.perf_counter()
+        for k, v in (("search", t1 - t0), ("select", t2 - t1), ("play", t3 - t2), ("game_end", t4 - t3)):
+            self.phase_s[k] = self.phase_s.get(k, 0.0) + v                        # wall-clock shares of a step (bench.py reports them)
         return h
 
     def step(self, selfplay=True):

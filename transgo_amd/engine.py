@@ -41,28 +41,51 @@ def choose_moves_reference(visits, steps, u, live, selfplay=True):
     return actions, pis
 
 
-def choose_moves_batch(visits, steps, u, live, selfplay=True):
-    G, A = visits.shape
-    actions = np.zeros(G, np.int32)
-    pis = np.zeros((G, A), np.float64)
-    idx = np.flatnonzero(live)
-    if len(idx) == 0:
-        return actions, pis
-    counts = visits[idx].astype(np.int64)
+def _choose_rows(counts_raw, steps, u, selfplay):
+    """self_play.py:666-683 for a block of live rows (see choose_moves_batch)."""
+    counts = counts_raw.astype(np.int64)
     counts = np.where(counts == 1, 0, counts)
     # No child visited twice (only possible when num_simulation is far below the number of legal moves): the reference
     # divides 0 by 0 here and np.random.choice raises on the NaN probabilities (self_play.py:671-683).  A batched engine
     # cannot afford one degenerate board stopping thousands, so such a row keeps its raw counts instead.
     dead = np.sum(counts, axis=1) == 0
     if dead.any():
-        counts[dead] = visits[idx][dead]
-    pis[idx] = counts / np.sum(counts, axis=1)[:, None]
-    inv_tau = np.array([1.0 / (temperature(int(s)) if selfplay else 0.12) for s in steps[idx]])
+        counts[dead] = counts_raw[dead]
+    pis = counts / np.sum(counts, axis=1)[:, None]
+    if selfplay:
+        inv_tau = 1.0 / (0.65 + (1.0 - 0.65) * np.array([math.exp(-1. * int(s) / 10) for s in steps]))     # configure.py:75-79, per game
+    else:
+        inv_tau = np.full(len(steps), 1.0 / 0.12)
     powed = np.power(counts, inv_tau[:, None])
     probs = powed / np.sum(powed, axis=1)[:, None]
     cdf = np.cumsum(probs, axis=1)
     cdf /= cdf[:, -1][:, None]
-    actions[idx] = (cdf <= u[idx][:, None]).sum(axis=1)          # searchsorted(u, 'right') on a non-decreasing row
+    return (cdf <= u[:, None]).sum(axis=1), pis                  # searchsorted(u, 'right') on a non-decreasing row
+
+
+_POOL = None
+
+
+def choose_moves_batch(visits, steps, u, live, selfplay=True):
+    """Every operation is element-wise or a last-axis reduction, so each row equals the per-game 1-D computation bit for bit;
+    large batches are cut into row blocks handled by a few threads (NumPy releases the GIL inside its loops)."""
+    global _POOL
+    G, A = visits.shape
+    actions = np.zeros(G, np.int32)
+    pis = np.zeros((G, A), np.float64)
+    idx = np.flatnonzero(live)
+    if len(idx) == 0:
+        return actions, pis
+    nblk = min(8, len(idx) // 256)
+    if nblk <= 1:
+        actions[idx], pis[idx] = _choose_rows(visits[idx], steps[idx], u[idx], selfplay)
+        return actions, pis
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=8)
+    parts = np.array_split(idx, nblk)
+    for part, (a, p) in zip(parts, _POOL.map(lambda ix: _choose_rows(visits[ix], steps[ix], u[ix], selfplay), parts)):
+        actions[part] = a; pis[part] = p
     return actions, pis
 
 

@@ -31,6 +31,7 @@ for i in range(STEPS):
         print(f"step {i+1}: finished {fin} games, mean length {np.mean(lens) if lens else 0:.1f}, errors {st['errors']}, "
               f"arena high-water {st['max_slots']}, {st['sims'] / (time.time() - t0):.0f} sims/s", flush=True)
 st = sp.engine.stats()
-assert st["errors"] == 0, st
+assert st["errors"] == 0 and sp.games_dropped == 0, (st, sp.games_dropped)
+print("arena high-water", st["max_slots"], "slots; truncated tree blocks", st["truncated_blocks"], "; games dropped", sp.games_dropped)
 assert fin >= G * (STEPS // (MAXSTEP + 5)), (fin, "fewer finished games than the ply limit guarantees")
 print("soak ok:", fin, "games; black/white wins", winners[1], winners[2], "; mean length", round(float(np.mean(lens)), 1) if lens else 0)

@@ -373,7 +373,10 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sg(const fl
     // barriers), so the dispatcher-like balance is kept while the next tile's first weights go out before the current tile's stores
     // and its residual / first B fragments right after them (+1.2-1.7 %).  At F = 128 (shorter tiles, three workgroups per CU) the
     // same loop costs 2 %, so there every workgroup takes exactly one tile.
-    constexpr bool PERSIST = F == 256;
+#ifndef TG_SG_PERSIST128
+#define TG_SG_PERSIST128 0
+#endif
+    constexpr bool PERSIST = F == 256 || TG_SG_PERSIST128;
     const int ntiles = (M + TM - 1) / TM;
     const int aoff = j * CC + ((kq ^ swz64(j)) << 2);
     unsigned vmask[NPT]; int boff[NPT];
@@ -1202,7 +1205,7 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                 }
                 const BlockW& b = n->blocks[L.ridx];
                 constexpr int SD_TM = F == 128 ? 192 : 128;
-                const int ntile_sd = (M + SD_TM - 1) / SD_TM, slots_sd = F == 128 ? ntile_sd : 512;  // F=256: 2 resident workgroups x 256 CUs walk a dynamic tile list
+                const int ntile_sd = (M + SD_TM - 1) / SD_TM, slots_sd = F == 128 ? (TG_SG_PERSIST128 ? 768 : ntile_sd) : 512;  // F=256: 2 resident workgroups x 256 CUs walk a dynamic tile list
                 const int grid_sd = ntile_sd < slots_sd ? ntile_sd : slots_sd;
                 int* const ctr1 = n->tile_ctr + 2 * L.ridx; int* const ctr2 = ctr1 + 1;              // zeroed at the top of the forward
                 float* const actn = act ? n->bufAct : (float*)nullptr;

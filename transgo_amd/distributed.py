@@ -50,6 +50,10 @@ def gather_harvest(h, S, C, dst=0, device_index=0):
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+        if nccl:
+            # wait() on an RCCL work item only orders torch's current stream behind the transfer; the received buffer is consumed
+            # next by libtransgo_hip on ITS OWN stream (tg_replay_append_dev), so the transfer must really be over
+            torch.cuda.synchronize(dev)
     if rank != dst:
         return []
     out = []

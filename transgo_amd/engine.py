@@ -92,8 +92,9 @@ def choose_moves_batch(visits, steps, u, live, selfplay=True):
 class SelfPlayEngine:
     def __init__(self, n_games, board_size=9, num_simulation=210, parallel_readouts=4, c_puct1=3, c_puct2=0.05,
                  wu_loss=2, komi=7.5, max_step=120, encode_dim=10, net_blocks=6, net_filters=128, arena_slots=0,
-                 device=0, evaluator=None, net_precision="f32"):
+                 device=0, evaluator=None, net_precision="f32", record_games=True):
         cfg = _lib.default_config()
+        cfg.record_games = 1 if record_games else 0       # per-move records in HBM for tg_sp_harvest (self-play); evaluation matches need none
         cfg.net_precision = {"f32": 0, "f16": 1}[net_precision]
         cfg.board_size, cfg.encode_dim, cfg.max_step, cfg.komi = board_size, encode_dim, max_step, komi
         cfg.n_games, cfg.num_simulation, cfg.parallel_readouts, cfg.wu_loss = n_games, num_simulation, parallel_readouts, wu_loss

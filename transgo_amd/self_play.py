@@ -275,7 +275,8 @@ class SelfPlay:
             half, board_size=cfg.board_size, num_simulation=cfg.num_simulation, parallel_readouts=cfg.parallel_readouts,
             c_puct1=cfg.c_puct1, c_puct2=cfg.c_puct2, wu_loss=cfg.wu_loss, komi=cfg.komi, max_step=cfg.max_step,
             encode_dim=cfg.encode_state_channels, net_blocks=w.blocks, net_filters=w.filters, device=w.device,
-            net_precision=getattr(cfg, "inference_dtype", "f32"), evaluator=evaluators[who] if evaluators else None)
+            net_precision=getattr(cfg, "inference_dtype", "f32"), evaluator=evaluators[who] if evaluators else None,
+            record_games=False)
         eng = {"train": mk("train"), "eval": mk("eval")}
         if not evaluators:
             for who, key in (("train", "weights"), ("eval", "evaluate_weights")):

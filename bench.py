@@ -125,8 +125,9 @@ def tree_roofline(S, C, sims, evals, depth_sum, children_scored, tree_ms, waves)
 
 def kernel_name(S, filters, dtype):
     """The F->F 3x3 conv kernel net.hip dispatches for this configuration (transgo_amd/csrc/net.hip: forward_t)."""
-    if dtype == "f16":
-        return f"k_conv3x3_h2<{S},{filters}> (fp16 operands, v_mfma_f32_16x16x32_f16, f32 accumulate, LDS-DMA fed)"
+    if dtype != "f32":
+        return (f"k_conv3x3_h2<{S},{filters}> (fp16 operands, v_mfma_f32_16x16x32_f16, f32 accumulate, LDS-DMA fed"
+                + (", fp16 residual stream)" if dtype == "f16r" else ")"))
     if filters in (128, 256) and os.environ.get("TG_DMA_CONV", "1") != "0":
         return f"k_conv3x3_sg<{S},{filters}> (fp32 MFMA 16x16x4 implicit GEMM; weights by LDS-DMA, activations straight from L2)"
     return f"k_conv3x3<{S},{filters},{filters}> (fp32 MFMA 16x16x4 implicit GEMM)"
@@ -156,7 +157,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=6)
     ap.add_argument("--board", type=int, default=9, help="board edge (9 = BASELINE configs[1]; 19 = configs[3])")
     ap.add_argument("--max-step", type=int, default=0, help="ply limit (default 120 at 9x9, 450 at 19x19)")
-    ap.add_argument("--dtype", choices=["f32", "f16"], default="f32",
+    ap.add_argument("--dtype", choices=["f32", "f16", "f16r"], default="f32",
                     help="network arithmetic: f32 (BASELINE metric, parity 1e-3) or f16 storage + f32 accumulate (configs[4])")
     ap.add_argument("--network", choices=["tower", "transgo"], default="tower",
                     help="tower = BASELINE.json's N-block x F-filter net; transgo = the reference's shipped MainNetwork (model.py:41-114)")
@@ -273,7 +274,7 @@ def main():
         value = sims_all / dt
         conv_tflops = (fl.value / (ms.value * 1e-3)) / 1e12 if ms.value > 0 else 0.0
         fpl = flops_per_leaf(S, 10, a.filters, a.blocks) if a.network == "tower" else None
-        peak = PEAK_F16_MATRIX_TFLOPS if a.dtype == "f16" else PEAK_F32_MATRIX_TFLOPS
+        peak = PEAK_F16_MATRIX_TFLOPS if a.dtype != "f32" else PEAK_F32_MATRIX_TFLOPS
         tree = tree_roofline(S, 10, sims, evals, depth, cs1.value - cs0.value, cms.value + ams.value, nw.value)
         if tree:
             tree["share_of_step"] = round((cms.value + ams.value) / (dt * 1e3), 4)

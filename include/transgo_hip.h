@@ -54,7 +54,8 @@ typedef struct tg_config {
     int32_t net_blocks;         /* residual blocks of the tower (BASELINE.json "N-block x F-filter") */
     int32_t net_filters;        /* channels F (multiple of 32) */
     int32_t device;             /* HIP device ordinal */
-    int32_t net_precision;      /* 0 = f32 network (default); 1 = fp16 weights/activations, f32 accumulate (BASELINE config 5) */
+    int32_t net_precision;      /* 0 = f32 network (default); 1 = fp16 weights/activations, f32 accumulate (BASELINE config 5), f32
+                                   residual stream; 2 = as 1 with the residual stream stored in fp16 too (a quarter less HBM traffic) */
     int32_t record_games;       /* 1 (default): every game's move record -- env.encode(root) bit-packed, raw visit counts, side to
                                    move; the three Python lists of self_play.py:917-926 -- is kept in HBM for tg_sp_harvest */
     int32_t reserved[6];

@@ -159,12 +159,14 @@ def seeded_tower(board_size=9, input_dim=10, filters=128, blocks=6, seed=1234):
     return net
 
 
-def half_storage_forward(net, x):
+def half_storage_forward(net, x, half_residual=False):
     """What an fp16-storage / f32-accumulate evaluation of `net` (a TowerNetwork) computes, with the rounding points of the
     HIP fp16 chain (BASELINE config 5): every convolution (stem, tower, the two head convs) takes fp16 weights (BatchNorm
     folded in f64, stored as f32, then rounded to nearest even) and fp16 inputs, products accumulate in f32; the residual
     stream and the dense heads stay f32.  Conv inputs: the 0/1 planes (exact), relu(bn1(x)) and relu(bn2(conv1(.))) inside a
-    PreActBlock, relu(bn_res_end(x)) for the head convs.  Only the accumulation order inside a convolution is left free."""
+    PreActBlock, relu(bn_res_end(x)) for the head convs.  Only the accumulation order inside a convolution is left free.
+    half_residual=True emulates net_precision 2: the residual stream is stored as fp16 as well -- a block's f32 result v feeds the
+    next activation unrounded, is rounded once into the stream, and the next block adds its convolution to that rounded value."""
     body = net.main_network
     P = body.S * body.S
     q = lambda t: t.half().float()
@@ -182,6 +184,7 @@ def half_storage_forward(net, x):
 
     with torch.no_grad():
         y = conv_bn_relu(body.conv1, x)
+        res = q(y) if half_residual else y                 # what the next block reads back as its residual
         for b in body.res_blocks:
             s1, t1 = fold(b.batchnormlize_1)
             s2, t2 = fold(b.batchnormlize_2)
@@ -189,7 +192,8 @@ def half_storage_forward(net, x):
             b1 = (b.conv_1.bias.double() * s2 + t2).float()
             a = q(F.relu(y * s1.float()[None, :, None, None] + t1.float()[None, :, None, None]))
             h = q(F.relu(F.conv2d(a, q(w1), b1, 1, 1)))
-            y = F.conv2d(h, q(b.conv_2.weight), b.conv_2.bias, 1, 1) + y
+            y = F.conv2d(h, q(b.conv_2.weight), b.conv_2.bias, 1, 1) + res
+            res = q(y) if half_residual else y
         se, te = fold(body.bn_res_end)
         z = q(F.relu(y * se.float()[None, :, None, None] + te.float()[None, :, None, None]))
         hid = F.relu(body.fc_val_own(conv_bn_relu(body.conv_val_own, z).view(-1, 2 * P)))

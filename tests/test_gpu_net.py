@@ -194,3 +194,29 @@ def test_background_weight_refresh_switches_sets_cleanly(precision, F):
         h.ctx.call("tg_net_load_poll", 1, ctypes.byref(pend))
         assert pend.value == 0
         assert same(h.main_prediction(x), want[k])
+
+
+@pytest.mark.parametrize("S,F,NB,n", [(9, 128, 4, 40), (19, 256, 3, 4), (9, 256, 40, 8)])
+def test_fp16_residual_stream_mode(S, F, NB, n):
+    """net_precision 2 ("f16r"): the residual stream is fp16 too (a third less HBM traffic per block).  Checked against the oracle's
+    emulation with the same rounding points (1e-3; only the order of summation inside a conv is free) and bounded against the plain
+    f32 tower (fp16 inference within ~5e-3 on probabilities) -- including a 40-block tower, where the rounding of the
+    stream accumulates."""
+    import torch
+    from oracle.net import half_storage_forward, seeded_tower
+    from transgo_amd.model import HipNetwork
+    torch.set_num_threads(8)
+    net = seeded_tower(S, 10, F, NB, seed=900 + NB)
+    x = _positions(S, n, 6)
+    p16, v16, o16 = [t.numpy() for t in half_storage_forward(net, torch.from_numpy(x), half_residual=True)]
+    with torch.no_grad():
+        p32, v32, o32 = [t.numpy() for t in net.main_prediction(torch.from_numpy(x))]
+    h = HipNetwork(S, 10, F, NB, rows_cap=16, precision="f16r")
+    h.set_weights(net.get_weights())
+    hp, hv, ho = h.main_prediction(x)
+    e16 = [float(np.abs(a - b).max()) for a, b in ((hp, p16), (hv, v16), (ho, o16))]
+    e32 = [float(np.abs(a - b).max()) for a, b in ((hp, p32), (hv, v32), (ho, o32))]
+    print(f"fp16-residual S={S} F={F} N={NB}: vs emulation policy {e16[0]:.2e} value {e16[1]:.2e} own {e16[2]:.2e}; "
+          f"vs f32 tower policy {e32[0]:.2e} value {e32[1]:.2e} own {e32[2]:.2e}")
+    assert max(e16) < 1e-3
+    assert e32[0] < 5e-3 and e32[1] < 2e-2 and e32[2] < 2e-2

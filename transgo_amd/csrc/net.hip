@@ -41,7 +41,7 @@ struct Net {
     float* bufQ = nullptr; float* hca = nullptr;   // q|k|v projections [rows][P][1.5F]; policy head conv output
     float* bufAct = nullptr;                       // pre-activated input of the next conv (DMA path)
     int* tile_ctr = nullptr;                       // [2*NB] tile counters of the persistent conv launches (zeroed per forward)
-    int prec = 0;                                  // cfg.net_precision: 0 = f32, 1 = fp16 storage + f32 accumulate (k_conv3x3_h)
+    int prec = 0;                                  // cfg.net_precision: 0 = f32, 1 = fp16 storage + f32 accumulate (k_conv3x3_h2), 2 = 1 + fp16 residual stream
     _Float16* stem_h = nullptr; _Float16* head_h = nullptr; _Float16* x0h = nullptr;   // fp16 path: stem [2*9][F][32] (16 planes padded to 64), head [F/32*9][16][32], input [rows][P][64]
     _Float16* wh = nullptr; _Float16* act16 = nullptr; _Float16* h16 = nullptr;   // fp16 path: weights [2*NB][F/32*9][F][32], activations [rows][P][F]
     int dma = 0;                                   // attention-free F=128/256 f32 tower: 1 = k_conv3x3_sg chain (default), 0 = k_conv3x3 (TG_DMA_CONV=0)
@@ -480,7 +480,7 @@ __device__ __forceinline__ void vmcnt_uniform(int n) {
     else if constexpr (N > 0) vmcnt_uniform<N - 1>(n);
 }
 
-template <int F, int CT, int NPT, int EPI>
+template <int F, int CT, int NPT, int EPI, bool R16 = false>
 __device__ __forceinline__ void conv_epilogue_h(f32x4 (&acc)[CT][NPT], const int (&mrow)[NPT], int M, int co_base, int kq,
                                                 float* __restrict__ out32, _Float16* __restrict__ out16,
                                                 const float* __restrict__ res, const float* par, int pstride) {
@@ -517,7 +517,16 @@ __device__ __forceinline__ void conv_epilogue_h(f32x4 (&acc)[CT][NPT], const int
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                     }
-                    if (out32) *reinterpret_cast<f32x4*>(out32 + (size_t)mrow[t] * F + col) = v;   // null: the last block (only its activation feeds the head)
+                    if (out32) {                                         // null: the last block (only its activation feeds the head)
+                        if (R16) {                                       // fp16 residual stream (net_precision 2), slice-major like the activations
+                            h4 xr;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) xr[e] = (_Float16)v[e];
+                            *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(out32) + h16_index(mrow[t], col, M)) = xr;
+                        } else {
+                            *reinterpret_cast<f32x4*>(out32 + (size_t)mrow[t] * F + col) = v;
+                        }
+                    }
                     if (out16) {
                         const f32x4 sc = *reinterpret_cast<const f32x4*>(par + pstride + lc);
                         const f32x4 sh = *reinterpret_cast<const f32x4*>(par + 2 * pstride + lc);
@@ -540,7 +549,7 @@ __device__ __forceinline__ void conv_epilogue_h(f32x4 (&acc)[CT][NPT], const int
 // reads chip-wide at 1 PFLOP/s).  Measured shares of a 0.88-ms launch (8192 boards, F=256; ablation builds): MFMA loop alone
 // 0.44, DMA issue + traffic 0.17, epilogue 0.22, B-fragment addressing + reads 0.09, barriers 0.03, A reads 0.03.
 // An 8-wave 256x256 tile with one workgroup per CU (64-channel stages) measured 827 vs 888 TFLOP/s for this shape.
-template <int S, int CIN, int F, int EPI>
+template <int S, int CIN, int F, int EPI, bool R16 = false>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restrict__ in, float* __restrict__ out32,
                                                        _Float16* __restrict__ out16, const float* __restrict__ res,
                                                        const _Float16* __restrict__ Ws, const float* __restrict__ bias,
@@ -647,7 +656,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (EPI == 1 && m < M) acc[ct][t] = *reinterpret_cast<const f32x4*>(res + (size_t)m * F + co0 + ct * 16 + kq * 4);
+                if (EPI == 1 && m < M) {
+                    if (R16) {
+                        const h4 rh = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(res) + h16_index(m, co0 + ct * 16 + kq * 4, M));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[ct][t][e] = (float)rh[e];
+                    } else {
+                        acc[ct][t] = *reinterpret_cast<const f32x4*>(res + (size_t)m * F + co0 + ct * 16 + kq * 4);
+                    }
+                }
             }
         }
         // first tile of a residual-free launch: only the prologue DMAs are in flight, so the wait can leave X(1), W(2), W(3) out;
@@ -708,7 +725,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
         while (nb < nblk && tile_m0(nb) >= M) nb += gridDim.x;
         const bool have_next = nb < nblk;
         if (have_next) { bid = nb; m0 = tile_m0(nb); prologue(); }
-        conv_epilogue_h<F, CT, NPT, (EPI == 1 ? 2 : EPI)>(acc, mrow, M, co0, kq, out32, out16, res, par, NCO);   // EPI 4: the stem
+        conv_epilogue_h<F, CT, NPT, (EPI == 1 ? 2 : EPI), R16>(acc, mrow, M, co0, kq, out32, out16, res, par, NCO);   // EPI 4: the stem
         if (!have_next) break;
     }
 }
@@ -1125,9 +1142,11 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
     if (n->prec == 0) hipLaunchKernelGGL((k_obs_to_rows<S>), dim3(g0), dim3(256), 0, st, obs, n->x0, rows, n->C);
     float* x = n->bufA; float* y = n->bufB;
     if constexpr (F == 128 || F == 256) {
-        if (n->prec == 1) {
-            // fp16 chain: every conv (stem, tower, head conv) takes fp16 operands and accumulates in f32; the residual stream x/y and
-            // the small dense heads (k_heads) stay f32
+        if (n->prec >= 1) {
+            // fp16 chain: every conv (stem, tower, head conv) takes fp16 operands and accumulates in f32; the small dense heads
+            // (k_heads) stay f32, and so does the residual stream x/y unless net_precision is 2 (then x/y are fp16, slice-major, and
+            // live in the same buffers; a block's output is still rounded once, from the f32 accumulator)
+            const bool r16 = n->prec == 2;
             if ((long long)M * F * 2 >= (1ll << 31)) TG_FAIL(ctx, TG_ERR_ARG, "fp16 path: rows * P * F * 2 bytes must stay below 2 GiB per activation buffer");
             const int grid_h = (M + 255) / 256;                                      // 256-row tiles
             constexpr int COS = F / 128;
@@ -1140,9 +1159,14 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
             // writes the f32 residual stream x and the first conv input relu(bn_next(x)) as fp16
             int g0h = (int)(((size_t)M * 64 + 255) / 256); if (g0h > 65535) g0h = 65535;
             hipLaunchKernelGGL((k_obs_to_rows_h<S>), dim3(g0h), dim3(256), 0, st, obs, n->x0h, rows, n->C);
-            hipLaunchKernelGGL((k_conv3x3_h2<S, 64, F, 4>), dim3(grid_h2), dim3(256), 0, st, (const _Float16*)n->x0h, x, n->act16,
-                               (const float*)nullptr, (const _Float16*)n->stem_h, n->stem.b, nb ? n->blocks[0].s1 : n->s_end,
-                               nb ? n->blocks[0].t1 : n->t_end, M, nblk_h2);
+            if (r16)
+                hipLaunchKernelGGL((k_conv3x3_h2<S, 64, F, 4, true>), dim3(grid_h2), dim3(256), 0, st, (const _Float16*)n->x0h, x, n->act16,
+                                   (const float*)nullptr, (const _Float16*)n->stem_h, n->stem.b, nb ? n->blocks[0].s1 : n->s_end,
+                                   nb ? n->blocks[0].t1 : n->t_end, M, nblk_h2);
+            else
+                hipLaunchKernelGGL((k_conv3x3_h2<S, 64, F, 4>), dim3(grid_h2), dim3(256), 0, st, (const _Float16*)n->x0h, x, n->act16,
+                                   (const float*)nullptr, (const _Float16*)n->stem_h, n->stem.b, nb ? n->blocks[0].s1 : n->s_end,
+                                   nb ? n->blocks[0].t1 : n->t_end, M, nblk_h2);
             for (size_t i = 0; i < nb; ++i) {
                 const BlockW& b = n->blocks[i];
                 const bool last = i + 1 == nb;
@@ -1153,8 +1177,12 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                   hipLaunchKernelGGL((k_conv3x3_h2<S, F, F, 0>), dim3(grid_h2), dim3(256), 0, st, (const _Float16*)n->act16,
                                      (float*)nullptr, n->h16, (const float*)nullptr, b.h1, b.c1.b, (const float*)nullptr, (const float*)nullptr, M, nblk_h2); }
                 { ProfScope ps(n, st, conv_flops);
-                  hipLaunchKernelGGL((k_conv3x3_h2<S, F, F, 1>), dim3(grid_h2), dim3(256), 0, st, (const _Float16*)n->h16,
-                                     last ? (float*)nullptr : y, a16, (const float*)x, b.h2, b.c2.b, sn, tn, M, nblk_h2); }
+                  if (r16)
+                      hipLaunchKernelGGL((k_conv3x3_h2<S, F, F, 1, true>), dim3(grid_h2), dim3(256), 0, st, (const _Float16*)n->h16,
+                                         last ? (float*)nullptr : y, a16, (const float*)x, b.h2, b.c2.b, sn, tn, M, nblk_h2);
+                  else
+                      hipLaunchKernelGGL((k_conv3x3_h2<S, F, F, 1>), dim3(grid_h2), dim3(256), 0, st, (const _Float16*)n->h16,
+                                         last ? (float*)nullptr : y, a16, (const float*)x, b.h2, b.c2.b, sn, tn, M, nblk_h2); }
                 float* t = x; x = y; y = t;
             }
             hipLaunchKernelGGL((k_head_h<S, F>), dim3(grid_h), dim3(256), 0, st, (const _Float16*)n->act16, n->hc,
@@ -1368,7 +1396,7 @@ int fill_weight_set(tg_ctx* ctx, Net* n, int k, const float* blob, hipStream_t s
     TG_HIP(ctx, hipMemcpyAsync(n->sets[k].blob, blob, sizeof(float) * n->blob_floats, hipMemcpyHostToDevice, st));
     Net view = *n;                                        // pointer fields of set k without disturbing the live binding
     bind_weights(&view, k);
-    if (n->prec == 1) {
+    if (n->prec >= 1) {
         // stage-ordered fp16 copies, converted on the device from the blob just uploaded (round to nearest even)
         for (const BlockW& b : view.blocks) {
             hipLaunchKernelGGL(k_restage_half, dim3(1024), dim3(256), 0, st, b.c1.w, const_cast<_Float16*>(b.h1), F, F, F, 32);   // k_conv3x3_h2: 32-channel stages
@@ -1434,13 +1462,13 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
     if (e->rows_cap > rows_cap) rows_cap = e->rows_cap;
     Net* n = e->net;
     const int prec = ctx->cfg.net_precision;
-    if (prec != 0 && prec != 1) TG_FAIL(ctx, TG_ERR_ARG, "net_precision: 0 (f32) or 1 (fp16 storage, f32 accumulate)");
+    if (prec < 0 || prec > 2) TG_FAIL(ctx, TG_ERR_ARG, "net_precision: 0 (f32), 1 (fp16 storage, f32 accumulate, f32 residual stream) or 2 (fp16 residual stream too)");
     if (n && (n->rows_cap < rows_cap || n->arch != arch || n->prec != prec)) { tg_net_destroy(ctx); n = nullptr; }
     const size_t P = (size_t)S * S, A = P + 1, Wq = (size_t)F / 4 * 2 + F;
     const bool any_att = pol || trunk.find('A') != std::string::npos;
     int NB = 0; for (char c : trunk) NB += c == 'R';
-    if (prec == 1 && (any_att || (F != 128 && F != 256)))
-        TG_FAIL(ctx, TG_ERR_ARG, "net_precision 1 (fp16) is built for attention-free towers with 128 or 256 filters");
+    if (prec >= 1 && (any_att || (F != 128 && F != 256)))
+        TG_FAIL(ctx, TG_ERR_ARG, "net_precision 1 / 2 (fp16) is built for attention-free towers with 128 or 256 filters");
     if (!n) {
         n = new Net();
         e->net = n;
@@ -1458,20 +1486,20 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
         if (pol) TG_HIP(ctx, hipMalloc((void**)&n->hca, sizeof(float) * (size_t)rows_cap * P * 16));
         // DMA-fed F->F chain: f32 towers of 128 / 256 filters, with or without attention layers (those need the 9x9 MFMA kernel)
         n->dma = ((F == 128 || F == 256) && (!any_att || S == 9)) ? (getenv("TG_DMA_CONV") ? (atoi(getenv("TG_DMA_CONV")) != 0) : 1) : 0;
-        if (prec == 1) n->dma = 0;
+        if (prec >= 1) n->dma = 0;
         const size_t wcopy = (size_t)(NB > 0 ? 2 * NB : 1) * 9 * F * F;
         if (n->dma) TG_HIP(ctx, hipMalloc((void**)&n->bufAct, act));
         if (n->dma) TG_HIP(ctx, hipMalloc((void**)&n->tile_ctr, sizeof(int) * (size_t)(NB > 0 ? 2 * NB : 1)));
         for (Net::WeightSet& w : n->sets) {
             TG_HIP(ctx, hipMalloc((void**)&w.blob, sizeof(float) * n_floats));
             if (n->dma) TG_HIP(ctx, hipMalloc((void**)&w.wstage, sizeof(float) * wcopy));
-            if (prec == 1) {
+            if (prec >= 1) {
                 TG_HIP(ctx, hipMalloc((void**)&w.wh, sizeof(_Float16) * wcopy));
                 TG_HIP(ctx, hipMalloc((void**)&w.stem_h, sizeof(_Float16) * 9 * (size_t)F * 64));
                 TG_HIP(ctx, hipMalloc((void**)&w.head_h, sizeof(_Float16) * 9 * 16 * (size_t)F));
             }
         }
-        if (prec == 1) {
+        if (prec >= 1) {
             TG_HIP(ctx, hipMalloc((void**)&n->act16, act / 2));
             TG_HIP(ctx, hipMalloc((void**)&n->h16, act / 2));
             TG_HIP(ctx, hipMalloc((void**)&n->x0h, sizeof(_Float16) * (size_t)rows_cap * P * 64));

@@ -19,6 +19,16 @@ using namespace tg;
 namespace {
 
 // ---- device helpers -------------------------------------------------------------------------------------------------------
+constexpr int kMaxPath = 512;                        // longest selection path kept in LDS (>= SearchCfg::maxd, checked at create)
+
+// The record lane `src` (wave-uniform) holds, for every lane.
+__device__ __forceinline__ NodeRec bcast_rec(const NodeRec& r, int src) {
+    struct Words { uint32_t w[8]; };
+    Words in = __builtin_bit_cast(Words, r), out;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out.w[i] = (uint32_t)__builtin_amdgcn_readlane((int)in.w[i], src);
+    return __builtin_bit_cast(NodeRec, out);
+}
 
 template <int S> __device__ __forceinline__ NodeRec* arena_of(NodeRec* base, int g, int half, int slots) {
     return base + ((size_t)g * 2 + half) * (size_t)slots;
@@ -165,12 +175,15 @@ __global__ __launch_bounds__(64) void k_begin(EngineDev d, int sims) {
     c->active = c->searching;
 }
 
+// 4096 boards = 16 single-wave workgroups per CU = 4 waves per SIMD: the register budget must let all of them be resident at once
+// (at 138 VGPRs only 12 fit and the kernel ran in two rounds).
 template <int S>
-__global__ __launch_bounds__(64) void k_collect(EngineDev d) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 : 1))) void k_collect(EngineDev d) {
     using G = Geo<S>;
     constexpr int HS = TreeGeo<S>::HS, NPASS = TreeGeo<S>::NPASS;
     __shared__ WaveLds<S> lds;
     __shared__ uint32_t mt_scratch[1248];
+    __shared__ int path_s[kMaxPath];                 // the path being walked (also written to HBM for k_absorb)
     const int g = blockIdx.x, lane = lane_id();
     GameCtl* c = &d.ctl[g];
     const SearchCfg& sc = d.sc;
@@ -190,13 +203,22 @@ __global__ __launch_bounds__(64) void k_collect(EngineDev d) {
     for (int attempt = 0; attempt < 2 * sc.R && npaths < sc.R && !err; ++attempt) {    // self_play.py:616
         int* path = paths + npaths * sc.maxd;
         int node = 0, depth = 0;
-        if (lane == 0) path[0] = 0;
+        if (lane == 0) { path[0] = 0; path_s[0] = 0; }
         NodeRec cur = arena[0];
-        int prev = -1;
+        int pblk = -1;                                                 // block of the leaf's parent (its header holds the parent's position)
         // ---- selection (self_play.py:623-627, :706-725) ----
+        // A level is ONE dependent HBM round trip: the node's child count and, speculatively, its first 64 child records are
+        // requested together (the count only masks them afterwards), and the chosen child's record is taken from the lane that
+        // already holds it.  (It used to be three: count, children, chosen child.)
         while (cur.flags & F_OPEN) {
             const int blk = cur.block;
+            NodeRec ch[NPASS];
+            const int i0 = blk + HS + lane;
+            if (i0 < sc.arena_slots) ch[0] = arena[i0];               // inside this game's arena whatever the child count is
             const int nchild = hdr_of<S>(arena, blk)->nchild;
+            pblk = blk;
+#pragma unroll
+            for (int j = 1; j < NPASS; ++j) { const int i = j * 64 + lane; if (i < nchild) ch[j] = arena[blk + HS + i]; }
             child_sum += nchild;
             const double sq = sqrt((double)(cur.n + cur.pending));
             double scv[NPASS];
@@ -205,7 +227,7 @@ __global__ __launch_bounds__(64) void k_collect(EngineDev d) {
             for (int j = 0; j < NPASS; ++j) {
                 const int i = j * 64 + lane;
                 scv[j] = -INFINITY;
-                if (i < nchild) { NodeRec ch = arena[blk + HS + i]; scv[j] = puct_score(ch, sq, sc); }
+                if (i < nchild) scv[j] = puct_score(ch[j], sq, sc);
                 best = scv[j] > best ? scv[j] : best;
             }
             best = wave_max(best);
@@ -221,12 +243,14 @@ __global__ __launch_bounds__(64) void k_collect(EngineDev d) {
                 if (k >= 0 && k < pc) { idx = j * 64 + nth_set_bit(tm[j], k); k = -1; }
                 else if (k >= 0) k -= pc;
             }
-            prev = node;
             node = blk + HS + idx;
             ++depth;
             if (depth >= sc.maxd || ntie == 0) { err |= 2; break; }
-            if (lane == 0) path[depth] = node;
-            cur = arena[node];
+            if (lane == 0) { path[depth] = node; path_s[depth] = node; }
+            const int src = __builtin_amdgcn_readfirstlane(idx & 63), pass = __builtin_amdgcn_readfirstlane(idx >> 6);
+#pragma unroll
+            for (int j = 0; j < NPASS; ++j)
+                if (pass == j) cur = bcast_rec(ch[j], src);
         }
         if (depth == 0) err |= 8;                                      // root must be expanded before searching
         if (err) break;
@@ -236,7 +260,7 @@ __global__ __launch_bounds__(64) void k_collect(EngineDev d) {
         if (cur.term) {                                                // cached terminal result
             const float v = cur.term == 1 ? 1.f : -1.f;
             __syncthreads();
-            for (int dd = lane; dd < len; dd += 64) backup_node(&arena[path[dd]], ((len - 1 - dd) & 1) ? -v : v);
+            for (int dd = lane; dd < len; dd += 64) backup_node(&arena[path_s[dd]], ((len - 1 - dd) & 1) ? -v : v);
             __syncthreads();
             ++sims;
             continue;
@@ -247,7 +271,7 @@ __global__ __launch_bounds__(64) void k_collect(EngineDev d) {
             // and evaluates it again (self_play.py:629-646); we reuse the first path's row.
             for (int q = 0; q < npaths; ++q) if (leafs[q] == node) { row = rows[q]; break; }
         } else {
-            BoardState<S> st = hdr_of<S>(arena, arena[prev].block)->st;
+            BoardState<S> st = hdr_of<S>(arena, pblk)->st;            // the parent's position
             bool ok;
             const bool done = state_step(bw, st, cur.action, d.rules, /*check=*/false, &ok);   // self_play.py:629
             if (done) {                                                // self_play.py:638-642
@@ -256,16 +280,18 @@ __global__ __launch_bounds__(64) void k_collect(EngineDev d) {
                 const float v = (st.next_player == winner) ? 1.f : -1.f;
                 if (lane == 0) arena[node].term = (v > 0.f) ? 1 : 2;
                 __syncthreads();
-                for (int dd = lane; dd < len; dd += 64) backup_node(&arena[path[dd]], ((len - 1 - dd) & 1) ? -v : v);
+                for (int dd = lane; dd < len; dd += 64) backup_node(&arena[path_s[dd]], ((len - 1 - dd) & 1) ? -v : v);
                 __syncthreads();
                 ++sims;
                 continue;
             }
+            // the evaluation-batch row is requested first: the atomic's round trip hides behind the flood fill below
+            const bool fits = free_slot + HS + G::A <= sc.arena_slots;  // room for the largest possible block: no row is taken in vain
+            if (!fits) { err |= 1; break; }
+            if (lane == 0) row = atomicAdd(&d.counters[CNT_ROWS], 1);
             bw.load_colors(st.bb[0], st.bb[1]);
             bw.analyze();
             const int blk = make_block(bw, st, arena, free_slot, sc.arena_slots, true);
-            if (blk < 0) { err |= 1; break; }
-            if (lane == 0) row = atomicAdd(&d.counters[CNT_ROWS], 1);
             row = __shfl(row, 0);
             encode_planes(bw, st, d.rules, d.obs + (size_t)row * d.rules.encode_dim * G::P);   // self_play.py:798
             if (lane == 0) {
@@ -277,7 +303,7 @@ __global__ __launch_bounds__(64) void k_collect(EngineDev d) {
         }
         leafs[npaths] = node; rows[npaths] = row;
         __syncthreads();
-        for (int dd = lane; dd < len; dd += 64) arena[path[dd]].pending += sc.wu;    // self_play.py:767-770
+        for (int dd = lane; dd < len; dd += 64) arena[path_s[dd]].pending += sc.wu;    // self_play.py:767-770
         if (lane == 0) { d.path_len[(size_t)g * sc.R + npaths] = len; d.path_row[(size_t)g * sc.R + npaths] = row; }
         __syncthreads();
         ++npaths;
@@ -616,6 +642,7 @@ int tg_engine_create(tg_ctx* ctx) {
     sc.R = R; sc.wu = cfg.wu_loss; sc.c1 = cfg.c_puct1; sc.c2 = cfg.c_puct2;
     sc.c1f = (float)cfg.c_puct1; sc.c2f = (float)cfg.c_puct2; sc.A = A;
     sc.maxd = ((cfg.max_step + 2 + 63) / 64) * 64;
+    if (sc.maxd > kMaxPath) TG_FAIL(ctx, TG_ERR_ARG, "max_step too large for the path buffer (at most 510)");
     long long slots = cfg.arena_slots > 0 ? cfg.arena_slots : (3LL * cfg.num_simulation + 256) * (HS + A);
     if (slots < 4LL * (HS + A) || slots > 0x3fffffffLL) TG_FAIL(ctx, TG_ERR_ARG, "arena_slots out of range");
     sc.arena_slots = (int)slots;

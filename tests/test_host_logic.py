@@ -124,6 +124,10 @@ def _gather_worker(rank, world, port, q):
     out = [x for hb in got for x in _summary(hb.records())]
     out1 = [x for hb in only1 for x in _summary(hb.records())]
     nbytes = [hb.nbytes for hb in got]
+    os.environ["TRANSGO_GATHER"] = "allgather"             # the fallback transport delivers the same batches
+    alt = [x for hb in gather_harvest(h, 9, 10, dst=0) for x in _summary(hb.records())]
+    os.environ.pop("TRANSGO_GATHER")
+    assert alt == out
     q.put((rank, out, _summary(recs), len(empty), blob.tolist(), out1, nbytes, h.nbytes))
     dist.destroy_process_group()
 

@@ -6,6 +6,8 @@ visit counts (pi = counts/sum is recomputed bit-identically at the owner), z, te
 per-game tables.  With RCCL the buffer is the very device tensor `tg_sp_harvest` filled, sent rank-to-rank at its exact
 length (grouped send/recv, no padding to the largest rank, no host staging); the 8-fold augmentation happens after the
 gather, at the consumer."""
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -39,6 +41,24 @@ def gather_harvest(h, S, C, dst=0, device_index=0):
             b = torch.from_numpy(b)
         return b.to(dev) if b.device != dev else b
 
+    if os.environ.get("TRANSGO_GATHER", "p2p") == "allgather":
+        # fallback transport (plain collective only): every rank contributes its buffer padded to the longest one
+        mx = max(records.layout(S, C, g, n)[1] if g else 0 for g, n in sizes)
+        pad = torch.zeros(mx, dtype=torch.uint8, device=dev)
+        if h is not None:
+            pad[:h.nbytes] = as_tensor(h)
+        bucket = [torch.empty(mx, dtype=torch.uint8, device=dev) for _ in range(world)]
+        dist.all_gather(bucket, pad)
+        if nccl:
+            torch.cuda.synchronize(dev)
+        if rank != dst:
+            return []
+        out = []
+        for r, (g, n) in enumerate(sizes):
+            if g:
+                nb = records.layout(S, C, g, n)[1]
+                out.append(h if r == dst else records.Harvest(S, C, g, n, bucket[r][:nb].clone() if nccl else bucket[r][:nb].numpy().copy()))
+        return out
     ops, recv = [], {}
     if rank == dst:
         for r, (g, n) in enumerate(sizes):

@@ -51,7 +51,12 @@ def _choose_rows(counts_raw, steps, u, selfplay):
     dead = np.sum(counts, axis=1) == 0
     if dead.any():
         counts[dead] = counts_raw[dead]
-    pis = counts / np.sum(counts, axis=1)[:, None]
+    tot = np.sum(counts, axis=1)
+    empty = tot == 0                                     # a slot that was never searched (parked / already over): pi = 0, action 0
+    if empty.any():
+        counts = counts.copy(); counts[empty, 0] = 1
+        tot = np.sum(counts, axis=1)
+    pis = counts / tot[:, None]
     if selfplay:
         inv_tau = 1.0 / (0.65 + (1.0 - 0.65) * np.array([math.exp(-1. * int(s) / 10) for s in steps]))     # configure.py:75-79, per game
     else:
@@ -60,7 +65,10 @@ def _choose_rows(counts_raw, steps, u, selfplay):
     probs = powed / np.sum(powed, axis=1)[:, None]
     cdf = np.cumsum(probs, axis=1)
     cdf /= cdf[:, -1][:, None]
-    return (cdf <= u[:, None]).sum(axis=1), pis                  # searchsorted(u, 'right') on a non-decreasing row
+    acts = (cdf <= u[:, None]).sum(axis=1)                      # searchsorted(u, 'right') on a non-decreasing row
+    if empty.any():
+        acts[empty] = 0; pis[empty] = 0.0
+    return acts, pis
 
 
 _POOL = None

@@ -656,21 +656,28 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (EPI == 1 && m < M) {
+                if (EPI == 1) {
+                    // always issued (rows past the batch re-read the last row and are never stored): the number of residual loads in
+                    // flight must be the same for every wave, because the wait below counts them
+                    const int mc = m < M ? m : M - 1;
                     if (R16) {
-                        const h4 rh = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(res) + h16_index(m, co0 + ct * 16 + kq * 4, M));
+                        const h4 rh = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(res) + h16_index(mc, co0 + ct * 16 + kq * 4, M));
 #pragma unroll
                         for (int e = 0; e < 4; ++e) acc[ct][t][e] = (float)rh[e];
                     } else {
-                        acc[ct][t] = *reinterpret_cast<const f32x4*>(res + (size_t)m * F + co0 + ct * 16 + kq * 4);
+                        acc[ct][t] = *reinterpret_cast<const f32x4*>(res + (size_t)mc * F + co0 + ct * 16 + kq * 4);
                     }
                 }
             }
         }
-        // first tile of a residual-free launch: only the prologue DMAs are in flight, so the wait can leave X(1), W(2), W(3) out;
-        // otherwise residual loads / the previous tile's stores are younger than them and everything is waited for
+        // first tile of a residual-free launch: only the prologue DMAs are in flight, so the wait can leave X(1), W(2), W(3) out.
+        // Residual variant: the CT*NPT residual loads are the YOUNGEST operations of the wave (the prologue DMAs and, in a persistent
+        // walk, the previous tile's stores are older), so waiting until only they are outstanding releases the first barrier as soon
+        // as the DMAs have landed; each accumulator's own load is then waited for by the compiler, in order, right before its first
+        // MFMA -- the 0.34-0.68 GB residual read no longer sits in front of the whole tile.
         if (EPI != 1 && first && NSL > 1) vmcnt_uniform<NXQ + 2 * WPW>((NXP - wave * NXQ < 0 ? 0 : NXP - wave * NXQ > NXQ ? NXQ : NXP - wave * NXQ) + 2 * WPW);
         else if (EPI != 1 && first) TG_VMCNT(2 * WPW);
+        else if (EPI == 1) TG_VMCNT(CT * NPT);
         else TG_VMCNT(0);
         first = false;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

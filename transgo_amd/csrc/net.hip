@@ -407,7 +407,8 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sg(const fl
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {                            // EPI 1: start from the residual (no loads behind the epilogue's stores)
                 acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (EPI == 1 && m < M) acc[ct][t] = *reinterpret_cast<const f32x4*>(res + (size_t)m * F + ct * 16 + kq * 4);
+                // always issued (rows past the batch re-read the last row; they are never stored): the wait at the loop head counts them
+                if (EPI == 1) acc[ct][t] = *reinterpret_cast<const f32x4*>(res + (size_t)(m < M ? m : M - 1) * F + ct * 16 + kq * 4);
             }
         }
         load_b(b_cur, 0);
@@ -417,7 +418,10 @@ __global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sg(const fl
     tile_setup();
     for (;;) {
         if (PERSIST && tid == 0) next_tile = (int)gridDim.x + atomicAdd(ctr, 1);    // read by everybody after the loop's barriers
-        TG_VMCNT(0);
+        // The barrier must see the weight DMAs of the first stages landed (and, in a persistent walk, the previous tile's stores
+        // gone); the operations tile_setup() issued after them -- CT*NPT residual loads, NPT B fragments -- are the wave's youngest
+        // and are waited for by the compiler, one by one, in front of the MFMA that first needs each.
+        TG_VMCNT((EPI == 1 ? CT * NPT : 0) + NPT);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         TG_BARRIER();
 

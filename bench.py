@@ -129,7 +129,8 @@ def kernel_name(S, filters, dtype):
         return (f"k_conv3x3_h2<{S},{filters}> (fp16 operands, v_mfma_f32_16x16x32_f16, f32 accumulate, LDS-DMA fed"
                 + (", fp16 residual stream)" if dtype == "f16r" else ")"))
     if filters in (128, 256) and os.environ.get("TG_DMA_CONV", "1") != "0":
-        return f"k_conv3x3_sg<{S},{filters}> (fp32 MFMA 16x16x4 implicit GEMM; weights by LDS-DMA, activations straight from L2)"
+        return (f"k_conv3x3_sg<{S},{filters}> (fp32 MFMA 16x16x4 implicit GEMM; weights by LDS-DMA, activations straight from L2"
+                + ("; 192- or 128-row tiles chosen per launch)" if filters == 128 else ")"))
     return f"k_conv3x3<{S},{filters},{filters}> (fp32 MFMA 16x16x4 implicit GEMM)"
 
 

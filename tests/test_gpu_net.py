@@ -220,3 +220,24 @@ def test_fp16_residual_stream_mode(S, F, NB, n):
           f"vs f32 tower policy {e32[0]:.2e} value {e32[1]:.2e} own {e32[2]:.2e}")
     assert max(e16) < 1e-3
     assert e32[0] < 5e-3 and e32[1] < 2e-2 and e32[2] < 2e-2
+
+
+def test_f32_conv_both_tile_shapes():
+    """k_conv3x3_sg at F = 128 is built with 192-row and 128-row tiles and the host picks per launch by the batch's round count:
+    1700 positions (137 700 rows: one round of 768 x 192, two of 1024 x 128) take the large tiles, 1500 (121 500 rows) the small
+    ones; both against fp32 torch, and the rows they share must agree bit for bit (the tile shape does not change the k order)."""
+    import torch
+    from oracle.net import seeded_tower
+    from transgo_amd.model import HipNetwork
+    torch.set_num_threads(8)
+    net = seeded_tower(9, 10, 128, 2, seed=31)
+    x = _positions(9, 1700, 12)
+    with torch.no_grad():
+        p, v, o = [t.numpy() for t in net.main_prediction(torch.from_numpy(x))]
+    h = HipNetwork(9, 10, 128, 2, rows_cap=1700)
+    h.set_weights(net.get_weights())
+    big = h.main_prediction(x)                       # M = 137700 -> 192-row tiles
+    small = h.main_prediction(x[:1500])              # M = 121500 -> 128-row tiles
+    for got, n in ((big, 1700), (small, 1500)):
+        assert np.abs(got[0] - p[:n]).max() < TOL and np.abs(got[1] - v[:n]).max() < TOL and np.abs(got[2] - o[:n]).max() < TOL
+    assert np.array_equal(big[0][:1500], small[0]) and np.array_equal(big[1][:1500], small[1])

@@ -128,6 +128,12 @@ def test_device_replay_sampler_equals_reference_buffer_plus_trainer_stacking():
     assert np.array_equal(ds, s) and np.array_equal(dp, p) and np.array_equal(dz, z) and np.array_equal(do, o)
     ds2, dp2, dz2, do2 = dev.sample(32)
     assert ds2.shape == (32, 10, 9, 9) and np.allclose(dp2.sum(1), 1, atol=1e-6)
+    # the device-resident form of the same batch (what a trainer on this GPU consumes): identical values, no host copy
+    ts, tp, tz, to = dev.sample_entries_device(idx)
+    assert ts.is_cuda and ts.dtype == torch.float32 and tuple(ts.shape) == (200, 10, 9, 9)
+    assert np.array_equal(ts.cpu().numpy(), s) and np.array_equal(tp.cpu().numpy(), p)
+    assert np.array_equal(tz.cpu().numpy(), z) and np.array_equal(to.cpu().numpy(), o)
+    assert tuple(dev.sample_device(16)[1].shape) == (16, 82)
     dev.close()
 
 

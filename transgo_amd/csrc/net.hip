@@ -339,14 +339,18 @@ __device__ __forceinline__ int swz64(int row) { return ((row >> 2) & 1) << 1; }
 // buffer offset, i.e. zeros) -- no activation slab in LDS, no zero-row select.  Everything is at least a stage old when it is
 // waited for, so each stage simply ends with s_waitcnt vmcnt(0).  An earlier design staged the activations as LDS slabs
 // (k_conv3x3_sd, one barrier per stage, 53 KB): 1-3.5 % slower on every shape, removed.
-template <int S, int F, int EPI>
-__global__ __launch_bounds__(256, (F == 128 ? 3 : 2)) void k_conv3x3_sg(const float* __restrict__ in, float* __restrict__ out,
+// NPT = position tiles per wave (rows per workgroup = 64*NPT).  F = 128 is built for 3 (192 rows, three workgroups per CU: the best
+// shape when the batch fills whole rounds of the 768 resident slots, e.g. exactly 16384 leaves = 9.0 rounds) and for 2 (128 rows,
+// four per CU, 1024 slots): in steady state a wave evaluates ~15.7 k leaves = 8.63 rounds of the first shape, whose partial last
+// round costs almost a full one; the host picks per launch whichever shape wastes less of its last round (+2 % in steady state).
+template <int S, int F, int EPI, int NPT_ = (F == 128 ? 3 : 2)>
+__global__ __launch_bounds__(256, (F == 128 ? (NPT_ == 3 ? 3 : 4) : 2)) void k_conv3x3_sg(const float* __restrict__ in, float* __restrict__ out,
                                                                        const float* __restrict__ res, const float* __restrict__ Ws,
                                                                        const float* __restrict__ bias, float* __restrict__ out2,
                                                                        const float* __restrict__ s2, const float* __restrict__ t2, int M,
                                                                        int* __restrict__ ctr) {
     constexpr int P = S * S, CT = F / 16, CC = 16;
-    constexpr int NPT = F == 128 ? 3 : 2, TM = 64 * NPT;
+    constexpr int NPT = NPT_, TM = 64 * NPT;
     constexpr int WPW = CT / 4;
     constexpr int NSL = F / CC, NST = NSL * 9, NG = TG_SG_NG, D = F == 128 ? 2 * NG : 4, NGS = D / 2, NGRP = NST / NGS;   // NGS stages per barrier, two groups resident
     static_assert((F == 128 || F == 256) && NST % NGS == 0, "tile geometry");
@@ -1243,17 +1247,32 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                     continue;
                 }
                 const BlockW& b = n->blocks[L.ridx];
-                constexpr int SD_TM = F == 128 ? 192 : 128;
-                const int ntile_sd = (M + SD_TM - 1) / SD_TM, slots_sd = F == 128 ? (TG_SG_PERSIST128 ? 768 : ntile_sd) : 512;  // F=256: 2 resident workgroups x 256 CUs walk a dynamic tile list
+                // tile shape per launch (F = 128): rows one full round of resident workgroups covers = 768 x 192 or 1024 x 128; take the
+                // shape whose rounded-up round count wastes fewer rows (ties: the larger tile)
+                bool small_tiles = false;
+                if constexpr (F == 128) {
+                    const long long r3 = 768LL * 192, r2 = 1024LL * 128;
+                    small_tiles = ((M + r2 - 1) / r2) * r2 < ((M + r3 - 1) / r3) * r3;
+                }
+                const int SD_TM = F == 128 ? (small_tiles ? 128 : 192) : 128;
+                const int ntile_sd = (M + SD_TM - 1) / SD_TM, slots_sd = F == 128 ? ntile_sd : 512;  // F=256: 2 resident workgroups x 256 CUs walk a dynamic tile list
                 const int grid_sd = ntile_sd < slots_sd ? ntile_sd : slots_sd;
                 int* const ctr1 = n->tile_ctr + 2 * L.ridx; int* const ctr2 = ctr1 + 1;              // zeroed at the top of the forward
                 float* const actn = act ? n->bufAct : (float*)nullptr;
                 { ProfScope ps(n, st, conv_flops);
-                  hipLaunchKernelGGL((k_conv3x3_sg<S, F, 0>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufAct, n->bufH,
-                                     (const float*)nullptr, b.g1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, ctr1); }
+                  if (small_tiles)
+                      hipLaunchKernelGGL((k_conv3x3_sg<S, F, 0, 2>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufAct, n->bufH,
+                                         (const float*)nullptr, b.g1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, ctr1);
+                  else
+                      hipLaunchKernelGGL((k_conv3x3_sg<S, F, 0>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufAct, n->bufH,
+                                         (const float*)nullptr, b.g1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, ctr1); }
                 { ProfScope ps(n, st, conv_flops);
-                  hipLaunchKernelGGL((k_conv3x3_sg<S, F, 1>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufH, y,
-                                     (const float*)x, b.g2, b.c2.b, actn, sn, tn, M, ctr2); }
+                  if (small_tiles)
+                      hipLaunchKernelGGL((k_conv3x3_sg<S, F, 1, 2>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufH, y,
+                                         (const float*)x, b.g2, b.c2.b, actn, sn, tn, M, ctr2);
+                  else
+                      hipLaunchKernelGGL((k_conv3x3_sg<S, F, 1>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufH, y,
+                                         (const float*)x, b.g2, b.c2.b, actn, sn, tn, M, ctr2); }
                 float* t = x; x = y; y = t;
             }
             // bufAct / bufH are slice-major; the head convs read the row-major residual stream and activate it while staging

@@ -138,6 +138,29 @@ class DeviceReplayMemory:
         self._lib.check(self.ctx.lib, self.ctx.h, self.ctx.lib.tg_replay_sample(self.h, p(entries), B, p(state), p(pi), p(z), p(own), 0))
         return state, pi, z, own
 
+    def sample_entries_device(self, entries):
+        """The same four arrays as torch float32 tensors in THIS GPU's memory (tg_replay_sample with device_out): what
+        trainer.py:50-54 builds with torch.FloatTensor(...).to(device), without the host round trip."""
+        import torch
+        entries = np.ascontiguousarray(entries, np.int64)
+        B = len(entries)
+        dev = torch.device("cuda", self.ctx.cfg.device)
+        state = torch.empty((B, self.C, self.S, self.S), dtype=torch.float32, device=dev); pi = torch.empty((B, self.A), dtype=torch.float32, device=dev)
+        z = torch.empty(B, dtype=torch.float32, device=dev); own = torch.empty((B, self.P), dtype=torch.float32, device=dev)
+        vp = self._ct.c_void_p
+        self._lib.check(self.ctx.lib, self.ctx.h, self.ctx.lib.tg_replay_sample(
+            self.h, entries.ctypes.data_as(vp), B, vp(state.data_ptr()), vp(pi.data_ptr()), vp(z.data_ptr()), vp(own.data_ptr()), 1))
+        return state, pi, z, own
+
+    def sample_device(self, batch_size):
+        return self.sample_entries_device(self._draw(batch_size))
+
+    def _draw(self, batch_size):                                     # replay_buffer.py:36-47: the index draw
+        buffer_len = self.info()["entries"]
+        if buffer_len < batch_size:
+            return np.random.choice(buffer_len, batch_size)
+        return np.random.choice(buffer_len, batch_size, replace=False)
+
     def sample(self, batch_size):                                    # replay_buffer.py:36-47
         buffer_len = self.info()["entries"]
         if buffer_len < batch_size:

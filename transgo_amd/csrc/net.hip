@@ -476,10 +476,14 @@ __global__ __launch_bounds__(256, (F == 128 ? (NPT_ == 3 ? 3 : 4) : 2)) void k_c
     }
 }
 
-// fp16 activation tensors are SLICE-MAJOR: [channels/32][M rows][32 halfs], so the 16 rows x 64 B of a slab DMA piece are one
-// contiguous KB (8 full 128-B lines) instead of 16 half-used lines 2F bytes apart -- measured, a row-major slab piece costs the
-// texture-address path ~3x a contiguous weight piece.  Element (row m, channel c):
-__device__ __forceinline__ size_t h16_index(int m, int c, int M) { return ((size_t)(c >> 5) * M + m) * 32 + (c & 31); }
+// fp16 activation tensors are CHUNK-MAJOR: [channels/32 slices][4 chunks of 8 channels][M rows][8 halfs].  A slab DMA piece (64 rows
+// x 16 B of one chunk plane) is one contiguous KB in memory (a row-major piece is 16 half-used lines 2F bytes apart and costs the
+// texture-address path ~3x as much), and the LDS image it builds -- plane after plane, rows 16 B apart -- is read by ds_read_b128
+// MFMA fragments without bank conflicts and WITHOUT a swizzle: lane (row j, chunk kq) reads plane kq at row R + j, the 16-lane
+// service groups of the instruction (MI355X_MICROARCH.md, LDS table) then cover 64 distinct banks as long as a plane is a multiple
+// of 16 rows, so a tap is a constant byte offset (round 1 kept rows of 64 B and XOR-swizzled the chunk index by the row, which cost
+// ~8 vector instructions of address arithmetic per fragment).  Element (row m, channel c):
+__device__ __forceinline__ size_t h16_index(int m, int c, int M) { return (((size_t)(c >> 5) * 4 + ((c >> 3) & 3)) * M + m) * 8 + (c & 7); }
 
 // s_waitcnt vmcnt(n) for a wave-uniform n in [0, N]: the instruction takes an immediate
 template <int N>
@@ -566,11 +570,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
     constexpr int NCHK = KC / 8, RPP = 64 / NCHK;                       // 4 chunks per 64-B row, 16 rows per 1-KB DMA piece
     constexpr int NSL = CIN / KC, NST = NSL * 9, NPAIR = NST / 2, NSLOT = 4;        // CIN input channels (row stride), F output channels
     constexpr int NROW = TM + 2 * HALO;
-    constexpr int NXP = (NROW + RPP - 1) / RPP;
+    constexpr int PLR = (NROW + 63) / 64 * 64;                          // rows of one chunk plane of the slab image (whole 1-KB pieces)
+    constexpr int NXP = NCHK * (PLR / 64);                              // slab pieces: 4 planes x PLR/64
     constexpr int NXQ = (NXP + NW - 1) / NW;
     constexpr int WPW = NCO / RPP / NW;                                 // weight pieces per wave per stage (2)
     static_assert(NST % 2 == 0 && CIN % KC == 0 && F % NCO == 0 && NCO % (RPP * NW) == 0, "tile geometry");
-    __shared__ __attribute__((aligned(16))) _Float16 xs[2][NXP * RPP * KC];
+    __shared__ __attribute__((aligned(16))) _Float16 xs[2][NCHK * PLR * 8];
     __shared__ __attribute__((aligned(16))) _Float16 ws[NSLOT][NCO * KC];
     __shared__ __attribute__((aligned(16))) float par[3 * NCO];
     __shared__ __attribute__((aligned(16))) float zrow[4];
@@ -591,23 +596,21 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
         par[i] = bias[co0 + i]; par[NCO + i] = out16 && s2 ? s2[co0 + i] : 0.f; par[2 * NCO + i] = out16 && t2 ? t2[co0 + i] : 0.f;
     }
     const u32x4 rin = tg_rsrc(in, (unsigned)M * CIN * 2);
-    // a piece is 16 rows x 64 B: lane -> row prow, physical chunk pchk, which holds logical chunk pchk ^ swz64(row); pieces start at
-    // multiples of 16 rows, so the lane's share of every source address is ONE register (the rest is wave-uniform)
+    // weight pieces: 16 rows (couts) x 64 B; lane -> row prow, physical chunk pchk, which holds logical chunk pchk ^ swz64(row)
     const int prow = lane / NCHK, pchk = lane % NCHK;
-    const int lane_x = (prow * KC + (pchk ^ swz64(prow)) * 8) * 2;        // bytes; slice-major input: rows of a slice are 64 B apart
     const int lane_w = prow * KC + (pchk ^ swz64(prow)) * 8;              // halfs, stage-tile rows are KC halfs apart
+    // slab pieces: 64 rows x 16 B of one chunk plane, contiguous in memory and in LDS (lane = row)
     auto dma_x = [&](int sl) {
 #pragma unroll
         for (int i = 0; i < NXQ; ++i) {
             const int q = wave * NXQ + i;
             if (q < NXP) {                                               // wave-uniform
-                if (q * RPP + prow < NROW) {
-                    // the whole offset must travel in voffset: soffset is not range-checked, and rows outside the tensor must read 0
-                    // rows before the tensor / past its end read 0 (bounds check); rows m < 0 or >= M of an inner slice read a
-                    // neighbouring slice's rows instead -- finite values that only masked taps could ever select
-                    const int voff = ((sl * M + m0 - HALO + q * RPP) * KC) * 2 + lane_x;
-                    tg_dma_buffer(rin, voff, (tg_lds_void*)(&xs[sl & 1][q * 512]));
-                }
+                const int plane = q / (PLR / 64), rg = q % (PLR / 64);
+                // the whole offset must travel in voffset: soffset is not range-checked, and rows outside the tensor must read 0
+                // (before its first plane / past its last one: bounds check).  Rows m < 0 or >= M of an inner plane read the
+                // neighbouring plane's rows instead -- finite values that only masked taps could ever select
+                const int voff = (((sl * NCHK + plane) * M + m0 - HALO + rg * 64) * 8) * 2 + lane * 16;
+                tg_dma_buffer(rin, voff, (tg_lds_void*)(&xs[sl & 1][(plane * PLR + rg * 64) * 8]));
             }
         }
     };
@@ -650,7 +653,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
 #pragma unroll
             for (int t = 0; t < NPT; ++t) {
                 const int R = vrow[t] + toff;
-                const _Float16* src = ((vmask[t] >> tap) & 1) ? base + R * KC + ((kq ^ swz64(R)) << 3)
+                const _Float16* src = ((vmask[t] >> tap) & 1) ? base + ((kq * PLR + R) << 3)
                                                               : reinterpret_cast<const _Float16*>(zrow);
                 b[t] = *reinterpret_cast<const f32x4*>(src);
             }
@@ -773,7 +776,7 @@ __global__ __launch_bounds__(256) void k_restage_f32(const float* __restrict__ w
     }
 }
 
-// network input for the fp16 stem: obs f32 [rows][C][P] (planes of 0/1, exact in fp16) -> x0h, 64 channels, slice-major (h16_index)
+// network input for the fp16 stem: obs f32 [rows][C][P] (planes of 0/1, exact in fp16) -> x0h, 64 channels, chunk-major (h16_index)
 template <int S>
 __global__ __launch_bounds__(256) void k_obs_to_rows_h(const float* __restrict__ obs, _Float16* __restrict__ x0, int rows, int C) {
     constexpr int P = S * S;
@@ -795,8 +798,9 @@ template <int S, int F>
 __global__ __launch_bounds__(256, 2) void k_head_h(const _Float16* __restrict__ in, float* __restrict__ out,
                                                    const _Float16* __restrict__ Wh, const float* __restrict__ bias, int M) {
     constexpr int P = S * S, HALO = S + 1, KC = 32, NW = 4, NPT = 4, TM = 64 * NW, NCHK = 4, RPP = 16;
-    constexpr int NSL = F / KC, NROW = TM + 2 * HALO, NXP = (NROW + RPP - 1) / RPP, NXQ = (NXP + NW - 1) / NW;
-    __shared__ __attribute__((aligned(16))) _Float16 xs[2][NXP * RPP * KC];
+    constexpr int NSL = F / KC, NROW = TM + 2 * HALO, PLR = (NROW + 63) / 64 * 64, NXP = NCHK * (PLR / 64), NXQ = (NXP + NW - 1) / NW;
+    static_assert(RPP == 16, "weight pieces are 16 couts x 64 B");
+    __shared__ __attribute__((aligned(16))) _Float16 xs[2][NCHK * PLR * 8];      // chunk-major slab image (see h16_index)
     __shared__ __attribute__((aligned(16))) _Float16 wsl[2][9 * 16 * KC];
     __shared__ __attribute__((aligned(16))) float zrow[4];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -806,15 +810,15 @@ __global__ __launch_bounds__(256, 2) void k_head_h(const _Float16* __restrict__ 
     if (tid < 4) zrow[tid] = 0.f;
     const u32x4 rin = tg_rsrc(in, (unsigned)M * F * 2);
     const int prow = lane / NCHK, pchk = lane % NCHK;
-    const int lane_x = (prow * KC + (pchk ^ swz64(prow)) * 8) * 2;      // slice-major input (h16_index)
     const int lane_w = prow * KC + (pchk ^ swz64(prow)) * 8;
     auto dma = [&](int sl) {                                              // slab and weight block of slice sl
 #pragma unroll
         for (int i = 0; i < NXQ; ++i) {
             const int q = wave * NXQ + i;
-            if (q < NXP && q * RPP + prow < NROW) {
-                const int voff = ((sl * M + m0 - HALO + q * RPP) * KC) * 2 + lane_x;
-                tg_dma_buffer(rin, voff, (tg_lds_void*)(&xs[sl & 1][q * 512]));
+            if (q < NXP) {                                               // wave-uniform: a piece = 64 rows x 16 B of one chunk plane
+                const int plane = q / (PLR / 64), rg = q % (PLR / 64);
+                const int voff = (((sl * NCHK + plane) * M + m0 - HALO + rg * 64) * 8) * 2 + lane * 16;
+                tg_dma_buffer(rin, voff, (tg_lds_void*)(&xs[sl & 1][(plane * PLR + rg * 64) * 8]));
             }
         }
 #pragma unroll
@@ -860,7 +864,7 @@ __global__ __launch_bounds__(256, 2) void k_head_h(const _Float16* __restrict__ 
 #pragma unroll
             for (int t = 0; t < NPT; ++t) {
                 const int R = vrow[t] + toff;
-                const _Float16* src = ((vmask[t] >> tap) & 1) ? base + R * KC + ((kq ^ swz64(R)) << 3) : reinterpret_cast<const _Float16*>(zrow);
+                const _Float16* src = ((vmask[t] >> tap) & 1) ? base + ((kq * PLR + R) << 3) : reinterpret_cast<const _Float16*>(zrow);
                 const f32x4 b = *reinterpret_cast<const f32x4*>(src);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a[tap]), __builtin_bit_cast(h8, b), acc[t], 0, 0, 0);
             }

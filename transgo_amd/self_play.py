@@ -78,8 +78,7 @@ class BatchedSelfPlay:
     lists (observations, visit counts, players; self_play.py:917-926) lives in HBM inside the engine; a finished game leaves
     it as a `records.Harvest` batch -- in device memory when the consumer is on the GPU too."""
 
-    def __init__(self, config, n_games, device=0, rank=0, world=1, evaluator=None, keep_obs=True, arena_slots=0,
-                 seed_fn=None):
+    def __init__(self, config, n_games, device=0, rank=0, world=1, evaluator=None, arena_slots=0, seed_fn=None):
         self.config, self.G, self.rank, self.world = config, n_games, rank, world
         self.S = config.board_size
         self.filters = getattr(config, "num_features", 128)

@@ -137,6 +137,31 @@ def _actor_worker(rank, world, port, q, backend):
         info = mem.info()
         out.update(steps=st.get_info("now_play_steps"), games=st.get_info("now_play_games"),
                    entries=info.get("entries", info["index"]))
+    # second scenario: the real network, weights published on rank 0 only -> packed there, broadcast, loaded in the background on
+    # every rank (self_play.py:913 for all actors at once); two weight versions, then both ranks must hold the second one
+    from transgo_amd import model
+    cfg2 = Config(num_simulation=8, max_step=30, num_features=32, num_blocks=2)
+    actor2 = SelfPlay(cfg2, n_games=2, device=gpu, rank=rank, world=world)
+    st2 = None
+    if rank == 0:
+        st2 = SharedStorage({"weights": model.random_weights(9, 10, 32, 2, seed=1), "now_play_steps": 0, "now_play_games": 0,
+                             "now_train_steps": 1, "train_play_ratio": 0.075, "adjust_train_play_ratio": False,
+                             "game_total_num": 1e8, "adjust_lr": False, "learn_rate": 1e-4}, cfg2)
+    actor2.continuous_self_play(st2, ReplayMemory_Random(cfg2) if rank == 0 else None, max_moves=2)
+    if rank == 0:
+        st2.set_info({"weights": model.random_weights(9, 10, 32, 2, seed=2), "now_train_steps": 2})
+    actor2.continuous_self_play(st2, ReplayMemory_Random(cfg2) if rank == 0 else None, max_moves=2)
+    import ctypes
+    pend = ctypes.c_int(-1)
+    actor2.worker.engine.ctx.call("tg_net_load_poll", 1, ctypes.byref(pend))
+    h = model.HipNetwork(9, 10, 32, 2, rows_cap=4, device=gpu)
+    h.set_weights(model.random_weights(9, 10, 32, 2, seed=2))
+    probe = (np.random.RandomState(5).rand(3, 10, 9, 9) < 0.2).astype(np.float32)
+    want = h.main_prediction(probe)
+    pol = np.empty((3, 82), np.float32); val = np.empty(3, np.float32)
+    actor2.worker.engine.ctx.call("tg_net_predict", probe.ctypes.data_as(ctypes.c_void_p), 3, pol.ctypes.data_as(ctypes.c_void_p),
+                                  val.ctypes.data_as(ctypes.c_void_p), None)
+    out["weights_ok"] = bool(np.array_equal(pol, want[0]) and np.array_equal(val, want[1].reshape(-1)))
     q.put(out)
     dist.destroy_process_group()
 
@@ -153,6 +178,7 @@ def _run_actor_ranks(backend):
     assert all(p.exitcode == 0 for p in ps)
     r0, r1 = res
     assert r0["dropped"] == r1["dropped"] == 0
+    assert r0["weights_ok"] and r1["weights_ok"]                      # the second weight version reached both ranks' GPUs
     assert r0["finished_local"] == 2 * 3 and r1["finished_local"] == 2 * 4
     assert r0["games"] == 14                                          # every rank's finished games reached the owner
     assert r0["entries"] == 14 * 5 * 8                                # 5 positions per game, 8 reference entries per position

@@ -328,3 +328,48 @@ def test_config_defaults_equal_the_reference(golden_dir):
         assert mine[k] == ref[k], k
     for step, t in ref["temperature_at"].items():
         assert temperature(int(step)) == t
+
+
+def test_weight_refresh_is_keyed_on_train_steps_and_content():
+    """`id(weights)` is not a version.  The actor asks for now_train_steps first, fetches + packs the weights only when
+    that counter moved, and uploads only when the packed content differs (SelfPlay._fetch_blob; no GPU needed: the engine is never
+    touched here)."""
+    import types
+    from transgo_amd.self_play import SelfPlay
+    sd1, sd2 = model.random_weights(9, 10, 32, 2, seed=1), model.random_weights(9, 10, 32, 2, seed=2)
+    fetched = []
+
+    class Storage:
+        def __init__(self):
+            self.d = {"weights": sd1, "now_train_steps": 5}
+
+        def get_info(self, k):
+            fetched.append(k)
+            return self.d[k]
+    st = Storage()
+    sp = SelfPlay.__new__(SelfPlay)
+    sp._train_steps_seen, sp._blob_digest = None, None
+    sp.worker = types.SimpleNamespace(S=9, filters=32, config=Config(), arch=model.tower_arch(2))
+    b = sp._fetch_blob(st)
+    assert b is not None and np.array_equal(b, model.pack_weights(sd1, 9, 10, 32, 2))
+    fetched.clear()
+    assert sp._fetch_blob(st) is None and fetched == ["now_train_steps"]          # counter unchanged: the weights are not even fetched
+    st.d["weights"] = dict(sd1)                                                   # a NEW dict object with the same content ...
+    st.d["now_train_steps"] = 6                                                   # ... published by a later train step
+    assert sp._fetch_blob(st) is None                                             # fetched, packed, same digest: no upload
+    st.d["weights"] = sd2; st.d["now_train_steps"] = 7
+    b2 = sp._fetch_blob(st)
+    assert b2 is not None and np.array_equal(b2, model.pack_weights(sd2, 9, 10, 32, 2))
+    st.d["weights"] = sd1                                                         # A -> B -> A again with a moving counter is an update too
+    st.d["now_train_steps"] = 8
+    assert sp._fetch_blob(st) is not None
+
+    class Bare:                                                                   # a storage without the counter is asked every time
+        def get_info(self, k):
+            if k == "now_train_steps":
+                raise KeyError(k)
+            return sd2
+    sp2 = SelfPlay.__new__(SelfPlay)
+    sp2._train_steps_seen, sp2._blob_digest = None, None
+    sp2.worker = sp.worker
+    assert sp2._fetch_blob(Bare()) is not None and sp2._fetch_blob(Bare()) is None

@@ -170,3 +170,16 @@ def test_plain_c_host_drives_the_engine_through_the_c_abi(tmp_path):
     assert out.returncode == 0 and "c_host_min ok" in out.stdout, out.stdout + out.stderr
     sims = int(out.stdout.split("c_host_min ok: ")[1].split()[0])
     assert sims >= 3 * 8 * 32
+
+
+def test_example_selfplay_to_trainer_runs():
+    """examples/selfplay_to_trainer.py: complete games -> device replay store -> mini-batches through the reference trainer's own
+    batch code and loss (trainer.py:46-72) -> the updated weights back into the engine."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("ex_sp2tr", os.path.join(root, "examples", "selfplay_to_trainer.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    losses = mod.main(games=16, sims=16, max_step=8, batch=64, steps=3)
+    assert len(losses) == 3 and all(np.isfinite(losses))

@@ -1084,58 +1084,85 @@ __global__ __launch_bounds__(256, TG_ATT_OCC) void k_attention_mfma(const float*
 }
 
 // Heads after the 3x3 head convs (hc[row][p][16]: channels 0-1 value/own, 2-5 policy; BN+ReLU already applied).
+// HR rows per workgroup (8 at 9x9, 2 at 19x19): the dense weights (fc_act alone is 4P x A floats = 106 KB at 9x9) are read once per workgroup and used
+// for all its rows -- with one row per workgroup the kernel moved 1.7 GB of L2 -> CU traffic per 16384 rows.  Every output is the
+// same k-ordered fmaf chain as before, whatever the batching, so a row's results do not depend on which rows share its workgroup.
+template <int S> struct HeadRows { static constexpr int N = S == 9 ? 8 : 2; };      // LDS: 6P + A + 64 floats per row
 template <int S>
 __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ hc, const float* __restrict__ hca, const float* __restrict__ w_vo,
                                                const float* __restrict__ b_vo, const float* __restrict__ w_v,
                                                const float* __restrict__ b_v, const float* __restrict__ w_o,
                                                const float* __restrict__ b_o, const float* __restrict__ w_a,
                                                const float* __restrict__ b_a, float* __restrict__ policy,
-                                               float* __restrict__ value, float* __restrict__ own) {
-    constexpr int P = S * S, A = P + 1;
-    __shared__ float hin[6 * P];
-    __shared__ float hid[64];
-    __shared__ float logit[A];
-    __shared__ float red[2];
-    const int row = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < 6 * P; i += 256) {           // channels 0-1 from the value conv, 2-5 from the policy conv
-        const int c = i / P, p = i % P;
-        hin[i] = (c < 2 ? hc : hca)[((size_t)row * P + p) * 16 + c];
+                                               float* __restrict__ value, float* __restrict__ own, int rows) {
+    constexpr int P = S * S, A = P + 1, HR = HeadRows<S>::N;
+    __shared__ float hin[HR][6 * P];
+    __shared__ float hid[HR][64];
+    __shared__ float logit[HR][A];
+    __shared__ float red[HR][2];
+    const int row0 = blockIdx.x * HR, tid = threadIdx.x;
+    const int nr = rows - row0 < HR ? rows - row0 : HR;
+    for (int i = tid; i < HR * 6 * P; i += 256) {      // channels 0-1 from the value conv, 2-5 from the policy conv
+        const int r = i / (6 * P), k = i % (6 * P), c = k / P, p = k % P;
+        hin[r][k] = r < nr ? (c < 2 ? hc : hca)[((size_t)(row0 + r) * P + p) * 16 + c] : 0.f;
     }
     __syncthreads();
     if (tid < 64) {                                                   // fc_val_own + ReLU (model.py:99)
-        float a = b_vo[tid];
-        for (int i = 0; i < 2 * P; ++i) a = fmaf(hin[i], w_vo[i * 64 + tid], a);
-        hid[tid] = a > 0.f ? a : 0.f;
+        float a[HR];
+#pragma unroll
+        for (int r = 0; r < HR; ++r) a[r] = b_vo[tid];
+        for (int i = 0; i < 2 * P; ++i) {
+            const float w = w_vo[i * 64 + tid];
+#pragma unroll
+            for (int r = 0; r < HR; ++r) a[r] = fmaf(hin[r][i], w, a[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < HR; ++r) hid[r][tid] = a[r] > 0.f ? a[r] : 0.f;
     }
     for (int o = tid; o < A; o += 256) {                              // fc_act (model.py:110)
-        float a = b_a[o];
-        const float* hi = hin + 2 * P;
-        for (int i = 0; i < 4 * P; ++i) a = fmaf(hi[i], w_a[(size_t)i * A + o], a);
-        logit[o] = a;
+        float a[HR];
+#pragma unroll
+        for (int r = 0; r < HR; ++r) a[r] = b_a[o];
+        for (int i = 0; i < 4 * P; ++i) {
+            const float w = w_a[(size_t)i * A + o];
+#pragma unroll
+            for (int r = 0; r < HR; ++r) a[r] = fmaf(hin[r][2 * P + i], w, a[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < HR; ++r) logit[r][o] = a[r];
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < nr) {
+        const int r = tid;
         float a = b_v[0];
-        for (int k = 0; k < 64; ++k) a = fmaf(hid[k], w_v[k], a);
-        value[row] = tanhf(a);                                        // model.py:101
-        float mx = logit[0];
-        for (int o = 1; o < A; ++o) mx = logit[o] > mx ? logit[o] : mx;
-        red[0] = mx;
+        for (int k = 0; k < 64; ++k) a = fmaf(hid[r][k], w_v[k], a);
+        value[row0 + r] = tanhf(a);                                   // model.py:101
+        float mx = logit[r][0];
+        for (int o = 1; o < A; ++o) mx = logit[r][o] > mx ? logit[r][o] : mx;
+        red[r][0] = mx;
     }
     if (own)
         for (int o = tid; o < P; o += 256) {                          // fc_own (model.py:102)
-            float a = b_o[o];
-            for (int k = 0; k < 64; ++k) a = fmaf(hid[k], w_o[k * P + o], a);
-            own[(size_t)row * P + o] = tanhf(a);
+            float a[HR];
+#pragma unroll
+            for (int r = 0; r < HR; ++r) a[r] = b_o[o];
+            for (int k = 0; k < 64; ++k) {
+                const float w = w_o[k * P + o];
+#pragma unroll
+                for (int r = 0; r < HR; ++r) a[r] = fmaf(hid[r][k], w, a[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < HR; ++r) if (r < nr) own[(size_t)(row0 + r) * P + o] = tanhf(a[r]);
         }
     __syncthreads();
-    const float mx = red[0];
-    for (int o = tid; o < A; o += 256) logit[o] = expf(logit[o] - mx);
+    for (int i = tid; i < HR * A; i += 256) { const int r = i / A, o = i % A; logit[r][o] = expf(logit[r][o] - red[r][0]); }
     __syncthreads();
-    if (tid == 0) { float s = 0.f; for (int o = 0; o < A; ++o) s += logit[o]; red[1] = s; }
+    if (tid < nr) { float s2 = 0.f; for (int o = 0; o < A; ++o) s2 += logit[tid][o]; red[tid][1] = s2; }
     __syncthreads();
-    const float inv = 1.f / red[1];
-    for (int o = tid; o < A; o += 256) policy[(size_t)row * A + o] = logit[o] * inv;    // softmax, model.py:111
+    for (int i = tid; i < nr * A; i += 256) {                          // softmax, model.py:111
+        const int r = i / A, o = i % A;
+        policy[(size_t)(row0 + r) * A + o] = logit[r][o] * (1.f / red[r][1]);
+    }
 }
 
 struct ProfScope {
@@ -1206,8 +1233,8 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
             }
             hipLaunchKernelGGL((k_head_h<S, F>), dim3(grid_h), dim3(256), 0, st, (const _Float16*)n->act16, n->hc,
                                (const _Float16*)n->head_h, n->head.b, M);
-            hipLaunchKernelGGL((k_heads<S>), dim3(rows), dim3(256), 0, st, (const float*)n->hc, (const float*)n->hc, n->w_vo, n->b_vo,
-                               n->w_v, n->b_v, n->w_o, n->b_o, n->w_a, n->b_a, policy, value, own);
+            hipLaunchKernelGGL((k_heads<S>), dim3((rows + HeadRows<S>::N - 1) / HeadRows<S>::N), dim3(256), 0, st, (const float*)n->hc, (const float*)n->hc, n->w_vo, n->b_vo,
+                               n->w_v, n->b_v, n->w_o, n->b_o, n->w_a, n->b_a, policy, value, own, rows);
             TG_HIP(ctx, hipGetLastError());
             return TG_OK;
         }
@@ -1289,8 +1316,8 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                                    (const float*)nullptr, n->head_a.w, n->head_a.b, (const float*)nullptr, (const float*)nullptr, M);
                 hca = n->hca;
             }
-            hipLaunchKernelGGL((k_heads<S>), dim3(rows), dim3(256), 0, st, (const float*)n->hc, hca, n->w_vo, n->b_vo,
-                               n->w_v, n->b_v, n->w_o, n->b_o, n->w_a, n->b_a, policy, value, own);
+            hipLaunchKernelGGL((k_heads<S>), dim3((rows + HeadRows<S>::N - 1) / HeadRows<S>::N), dim3(256), 0, st, (const float*)n->hc, hca, n->w_vo, n->b_vo,
+                               n->w_v, n->b_v, n->w_o, n->b_o, n->w_a, n->b_a, policy, value, own, rows);
             TG_HIP(ctx, hipGetLastError());
             return TG_OK;
         }
@@ -1340,8 +1367,8 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                            (const float*)nullptr, n->head_a.w, n->head_a.b, (const float*)nullptr, (const float*)nullptr, M);
         hca = n->hca;
     }
-    hipLaunchKernelGGL((k_heads<S>), dim3(rows), dim3(256), 0, st, (const float*)n->hc, hca, n->w_vo, n->b_vo, n->w_v, n->b_v,
-                       n->w_o, n->b_o, n->w_a, n->b_a, policy, value, own);
+    hipLaunchKernelGGL((k_heads<S>), dim3((rows + HeadRows<S>::N - 1) / HeadRows<S>::N), dim3(256), 0, st, (const float*)n->hc, hca, n->w_vo, n->b_vo, n->w_v, n->b_v,
+                       n->w_o, n->b_o, n->w_a, n->b_a, policy, value, own, rows);
     TG_HIP(ctx, hipGetLastError());
     return TG_OK;
 }

@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""rocprofv3 --pmc counter_collection CSVs -> per-kernel JSON summary for profiles/ (medians over the launches of the LAST bench
-step: the tail of each kernel's dispatch sequence, so the staggering prelude's small searches are left out).
-usage: pmc_json.py <fetch_dir> <write_dir> <launches_per_step_conv> <waves_per_step> [out.json]"""
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/collect_profiles.sh -> profiles/r2_pmc_traffic.json.
+usage: pmc_json.py [gpurun_out/prof_r2] [out.json]"""
 import collections, csv, glob, json, statistics, sys
+
+ROOT = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r2"
+OUT = sys.argv[2] if len(sys.argv) > 2 else "profiles/r2_pmc_traffic.json"
+F = 128
 
 
 def load(d, counter):
@@ -12,35 +15,49 @@ def load(d, counter):
             if r["Counter_Name"] != counter:
                 continue
             k = r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0]
-            per[k].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), float(r["End_Timestamp"]) - float(r["Start_Timestamp"]),
-                           int(r["Grid_Size"])))
+            per[k].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), float(r["End_Timestamp"]) - float(r["Start_Timestamp"]), int(r["Grid_Size"])))
     return {k: sorted(v) for k, v in per.items()}
 
 
-def main():
-    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-    n_conv, n_wave = int(sys.argv[3]), int(sys.argv[4])
-    out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 1 --warmup 1 "
-                     "--no-cpu-baseline`; medians over the launches of the last (timed) step",
-           "correction": "FETCH_SIZE doubled (gfx950 tallies 128-B requests as 64 B: MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact; "
-                         "counter unit KB", "kernels": {}}
-    for k in sorted(set(fetch) | set(write)):
-        tail = n_conv if "k_conv3x3_sg" in k or "k_conv3x3_h2" in k else n_wave
-        f = [x for x in fetch.get(k, [])][-tail:]
-        w = [x for x in write.get(k, [])][-tail:]
-        if not f or not w:
-            continue
-        fk, wk = statistics.median(x[1] for x in f), statistics.median(x[1] for x in w)
-        out["kernels"][k] = {"launches_summarised": len(f), "grid_size_median": statistics.median(x[3] for x in f),
-                             "FETCH_SIZE_KB_raw_median": round(fk, 1), "WRITE_SIZE_KB_median": round(wk, 1),
-                             "hbm_bytes_per_launch": round((2 * fk + wk) * 1024.0, 1),
-                             "duration_us_median": round(statistics.median(x[2] for x in f) / 1e3, 2)}
-    s = json.dumps(out, indent=1)
-    if len(sys.argv) > 5:
-        open(sys.argv[5], "w").write(s + "\n")
+fe, wr = load(ROOT + "/fetch", "FETCH_SIZE"), load(ROOT + "/write", "WRITE_SIZE")
+out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, scripts/collect_profiles.sh) on `python3 bench.py "
+                 "--steps 1 --warmup 1 --no-cpu-baseline`; medians over the launches of the last (timed) step -- for the conv kernel over its "
+                 "full-batch launches (grid within 5 % of the largest)",
+       "correction": "FETCH_SIZE doubled (gfx950 tallies 128-B requests as 64 B: MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact; counter unit KB",
+       "kernels": {}}
+for k in sorted(set(fe) | set(wr)):
+    if not k.startswith("k_"):
+        continue
+    conv = "k_conv3x3_sg" in k
+    f, w = fe.get(k, []), wr.get(k, [])
+    if not f or not w:
+        continue
+    if conv:
+        f = [x for x in f if x[3] >= 0.95 * max(y[3] for y in f)][-600:]
+        w = [x for x in w if x[3] >= 0.95 * max(y[3] for y in w)][-600:]
     else:
-        print(s)
-
-
-if __name__ == "__main__":
-    main()
+        f, w = f[-101:], w[-101:]
+    fk, wk, grid = statistics.median(x[1] for x in f), statistics.median(x[1] for x in w), statistics.median(x[3] for x in f)
+    e = {"launches_summarised": len(f), "grid_size_median": grid, "FETCH_SIZE_KB_raw_median": round(fk, 1), "WRITE_SIZE_KB_median": round(wk, 1),
+         "hbm_bytes_per_launch": round((2 * fk + wk) * 1024.0, 1), "duration_us_median": round(statistics.median(x[2] for x in f) / 1e3, 2)}
+    if conv:
+        npt, epi = int(k.split(",")[3].strip(" >")), int(k.split(",")[2])
+        rows = grid / 256 * 64 * npt
+        alg = (8 * F if epi == 0 else 16 * F) * rows
+        e.update(tile_rows=64 * npt, rows_per_launch_approx=int(rows), algorithmic_bytes_per_launch=int(alg),
+                 traffic_over_algorithmic=round(e["hbm_bytes_per_launch"] / alg, 3))
+    out["kernels"][k] = e
+convs = [v for k, v in out["kernels"].items() if "k_conv3x3_sg" in k and v["launches_summarised"] > 50]
+out["dominant_kernel"] = ("k_conv3x3_sg<9,128,EPI,NPT> (EPI 0: relu; EPI 1: residual + next block's activated input; NPT 3 / 2: 192- / 128-row "
+                          "tiles, chosen per launch)")
+out["hbm_bytes_per_launch_mean"] = sum(v["hbm_bytes_per_launch"] for v in convs) / len(convs)
+out["algorithmic_bytes_per_launch_mean"] = sum(v["algorithmic_bytes_per_launch"] for v in convs) / len(convs)
+tc, ta = out["kernels"]["k_collect<9>"], out["kernels"]["k_absorb<9>"]
+out["tree_stage"] = {"hbm_bytes_per_wave": tc["hbm_bytes_per_launch"] + ta["hbm_bytes_per_launch"],
+                     "note": "k_collect + k_absorb per search wave (4096 games x up to 4 read-outs, ~16 k simulations); bench.py prices the same wave at "
+                             "bytes_per_sim x sims (roofline_tree); the 32-B-record reads are outside the FETCH_SIZE calibration, so treat the ratio as indicative"}
+json.dump(out, open(OUT, "w"), indent=1)
+for k, v in out["kernels"].items():
+    if "conv3x3_sg" in k:
+        print(k, v["launches_summarised"], v["duration_us_median"], v["hbm_bytes_per_launch"], v.get("traffic_over_algorithmic"))
+print(out["hbm_bytes_per_launch_mean"], out["tree_stage"]["hbm_bytes_per_wave"])

@@ -112,3 +112,52 @@ def test_finished_positions_and_empty_harvest():
     with pytest.raises(TransgoError):
         mem.sample_entries([0])                                # empty store
     mem.close(); eng.close()
+
+
+def test_c_abi_refuses_bad_calls_with_a_message():
+    """Error behaviour of the boundary (include/transgo_hip.h): bad configurations and out-of-order calls come back as a negative
+    status with tg_last_error set -- never a crash, never a silent fallback."""
+    from transgo_amd import _lib
+    from transgo_amd._lib import TransgoError
+    from transgo_amd.engine import SelfPlayEngine
+    cfg = _lib.default_config(); cfg.board_size = 13
+    with pytest.raises(TransgoError, match="board_size"):
+        _lib.Context(cfg)
+    cfg = _lib.default_config(); cfg.n_games = 2; cfg.max_step = 2000
+    with pytest.raises(TransgoError, match="max_step"):
+        _lib.Context(cfg)
+    eng = SelfPlayEngine(2, num_simulation=8, evaluator=evaluators.flat, record_games=False)
+    with pytest.raises(TransgoError, match="first reset"):
+        eng.ctx.call("tg_sp_reset", np.zeros(2, np.uint32).ctypes.data_as(ctypes.c_void_p), np.ones(2, np.uint8).ctypes.data_as(ctypes.c_void_p))
+    eng.reset([1, 2])
+    with pytest.raises(TransgoError, match="no leaf batch"):
+        eng.ctx.call("tg_sp_absorb")
+    eng.search()
+    vis, st = eng.root_visits()
+    bad = np.full(2, 81, np.int32)                             # pass is not among the root's children while board moves exist
+    done = np.zeros(2, np.uint8)
+    eng.ctx.call("tg_sp_play", bad.ctypes.data_as(ctypes.c_void_p), done.ctypes.data_as(ctypes.c_void_p))
+    assert list(done) == [2, 2] and (eng.game_errors() & 4).all()          # refused per game, reported, the engine stays usable
+    eng._evaluate(); eng.ctx.call("tg_sp_expand_roots")                    # close the (empty) root batch tg_sp_play opened
+    eng.reset([3, 4], np.ones(2, np.uint8))
+    eng.search(); vis, st = eng.root_visits()
+    assert eng.play(eng.choose_moves(vis, st)[0]).sum() == 0 and eng.stats()["errors"] == 0
+    with pytest.raises(TransgoError, match="record_games"):
+        _force_harvest()
+    blob = np.zeros(10, np.float32)
+    with pytest.raises(TransgoError, match="blob size"):
+        eng.ctx.call("tg_net_load", blob.ctypes.data_as(ctypes.c_void_p), blob.size, 0)
+    eng.close()
+
+
+def _force_harvest():
+    """tg_sp_harvest on a context created without game records, with a finished game pending."""
+    from transgo_amd.engine import SelfPlayEngine
+    e2 = SelfPlayEngine(1, num_simulation=8, max_step=1, evaluator=evaluators.flat, record_games=False)
+    e2.reset([5]); e2.search()
+    vis, st = e2.root_visits()
+    assert e2.play(e2.choose_moves(vis, st)[0]).all()
+    try:
+        e2.harvest()
+    finally:
+        e2.close()

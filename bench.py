@@ -106,15 +106,16 @@ def tree_roofline(S, C, sims, evals, depth_sum, children_scored, tree_ms, waves)
     """Second regime of SURVEY.md 8(d): selection / leaf step / expansion / backup are scan-and-graph work priced in HBM bytes.
     Algorithmic bytes per simulation with the mean depth d and mean fan-out a measured in this run (rank 0's games):
     selection d*(a+1)*32 (one 32-B record per child scored + the parent) + path updates 2*(d+1)*16*2 (pending then backup, read
-    and write) + board state 2*state + legal mask 2*ceil(A/8) + feature planes written C*P*4 + policy/value read (A+1)*4 +
-    expansion a*32; time = HIP events around every k_collect and k_absorb launch."""
+    and write) + board state 2*state + legal mask 2*ceil(A/8) + feature planes written bit-packed ceil(C*P/32)*4 (the evaluation
+    batch; round 1 wrote float planes, C*P*4) + policy/value read (A+1)*4 + expansion a*32; time = HIP events around every
+    k_collect and k_absorb launch."""
     if sims <= 0 or tree_ms <= 0:
         return None
     P, A = S * S, S * S + 1
     d = depth_sum / sims
     a = children_scored / max(1.0, depth_sum)
     state = 48 if S == 9 else 112
-    per_eval = C * P * 4 + (A + 1) * 4 + a * 32 + 2 * ((A + 7) // 8)
+    per_eval = ((C * P + 31) // 32) * 4 + (A + 1) * 4 + a * 32 + 2 * ((A + 7) // 8)
     bytes_per_sim = d * (a + 1) * 32 + 2 * (d + 1) * 16 * 2 + 2 * state + per_eval * (evals / sims)
     gbs = sims * bytes_per_sim / (tree_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 5),

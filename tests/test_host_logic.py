@@ -291,7 +291,7 @@ def test_bench_rooflines_are_computed_from_measured_inputs():
     assert bench.flops_per_leaf(19, 10, 256, 20) == pytest.approx(17.06e9, rel=1e-3)
     t = bench.tree_roofline(9, 10, sims=1000, evals=1000, depth_sum=2000, children_scored=160000, tree_ms=10.0, waves=5)
     d, a = 2.0, 80.0
-    per_eval = 10 * 81 * 4 + 83 * 4 + a * 32 + 2 * 11
+    per_eval = 26 * 4 + 83 * 4 + a * 32 + 2 * 11                 # 810 plane bits = 26 words
     want = d * (a + 1) * 32 + 2 * (d + 1) * 32 + 96 + per_eval
     assert t["bytes_per_sim"] == pytest.approx(want, abs=0.1) and t["mean_fanout"] == 80.0 and t["mean_depth"] == 2.0
     assert t["achieved"] == pytest.approx(1000 * want / 10e-3 / 1e9, abs=0.06) and t["bound"] == "hbm"      # reported to 0.1 GB/s

@@ -17,9 +17,17 @@ struct EngineDev {
     tg_mt19937* rng = nullptr;      // [G]  NumPy-legacy MT19937 stream per game
     int32_t* path_nodes = nullptr;  // [G][R][maxd]
     int32_t* path_len = nullptr;    // [G][R]
-    int32_t* path_row = nullptr;    // [G][R]  row of the evaluation batch that serves the path
-    int32_t* row_game = nullptr;    // [rows_cap]
-    float* obs = nullptr;           // [rows_cap][C][P]   evaluation batch, reference plane layout
+    int32_t* path_row = nullptr;    // [G][R]  slot (0..R-1) of the game's evaluation-batch entry that serves the path
+    // Evaluation batch.  Game g writes the positions it wants evaluated into ITS OWN slots g*R + 0.. (env.encode bit-packed,
+    // obs_words u32 each) and their number into game_nslot[g]; k_compact then turns the counts into dense rows: game_off[g] =
+    // first row of game g, row_slot[row] = slot.  Rows are therefore ordered by game (deterministic), nothing is allocated with
+    // atomics (round 1: ~16 k increments of one counter per wave cost a fifth of the tree stage), and the batch costs 104 B per
+    // position instead of 3240 B of float planes; the network's input kernel gathers through row_slot.
+    uint32_t* obs_bits = nullptr;   // [rows_cap = G*R][obs_words]
+    int32_t* game_nslot = nullptr;  // [G]
+    int32_t* game_off = nullptr;    // [G]
+    int32_t* row_slot = nullptr;    // [rows_cap]
+    uint8_t* game_act = nullptr;    // [G]  game was below its visit target when the wave started
     float* policy = nullptr;        // [rows_cap][A]
     float* value = nullptr;         // [rows_cap]
     int32_t* counters = nullptr;    // [CNT_N]
@@ -27,7 +35,7 @@ struct EngineDev {
     uint32_t* hist_obs = nullptr;   // [G][hist_T][obs_words]  env.encode(root) bit-packed (bit i = plane-major flat index i)
     int32_t* hist_cnt = nullptr;    // [G][hist_T][A]          raw root visit counts
     uint8_t* hist_pl = nullptr;     // [G][hist_T]             side to move
-    int hist_T = 0, obs_words = 0;
+    int hist_T = 0, obs_words = 0, G = 0;
     SearchCfg sc;
     RulesCfg rules;
 };
@@ -54,6 +62,7 @@ struct Engine {
     int fin_positions = 0;
     int32_t* d_fin = nullptr;        // [2][G] device copy of fin_slot / fin_off
     DevBuf hv_obs, hv_cnt, hv_z, hv_own, hv_pl, hv_game;   // harvest staging when the caller wants host arrays
+    DevBuf obs_f32;                  // float planes of the pending batch, only materialised for tg_sp_batch_obs (tests, host evaluators)
     std::vector<double> h_noise;
     std::vector<int32_t> h_nchild;
     Net* net = nullptr;
@@ -64,6 +73,6 @@ struct Engine {
 
 }  // namespace tg
 
-extern "C" int tg_net_forward(tg_ctx* ctx, int rows);   // obs[rows] -> policy[rows], value[rows] on ctx->stream
+extern "C" int tg_net_forward(tg_ctx* ctx, int rows);   // pending batch (obs_bits through row_slot) -> policy[rows], value[rows] on ctx->stream
 extern "C" void tg_net_destroy(tg_ctx* ctx);
 extern "C" int tg_net_load_arch(tg_ctx* ctx, const char* arch, const float* blob, size_t n_floats, int rows_cap);

@@ -88,6 +88,8 @@ __global__ __launch_bounds__(64) void k_reset(EngineDev d, const uint8_t* mask, 
     using G = Geo<S>;
     __shared__ WaveLds<S> lds;
     const int g = blockIdx.x;
+    __shared__ uint32_t bits_s[(13 * G::P + 31) / 32];
+    if (lane_id() == 0) d.game_nslot[g] = 0;
     if (mask && !mask[g]) {
         if (states && lane_id() == 0) { d.ctl[g].finished = 1; d.ctl[g].searching = 0; d.ctl[g].need_eval = 0; }
         return;
@@ -105,21 +107,16 @@ __global__ __launch_bounds__(64) void k_reset(EngineDev d, const uint8_t* mask, 
     bw.analyze();
     int free_slot = 1;
     int blk = make_block(bw, st, arena, free_slot, d.sc.arena_slots, !over);
-    int row = 0;
-    if (!over) {
-        if (bw.lane == 0) row = atomicAdd(&d.counters[CNT_ROWS], 1);
-        row = __shfl(row, 0);
-        encode_planes(bw, st, d.rules, d.obs + (size_t)row * d.rules.encode_dim * G::P);
-    }
+    if (!over) encode_bits(bw, st, d.rules, bits_s, d.obs_bits + (size_t)g * d.sc.R * d.obs_words);      // the game's slot 0
     if (bw.lane == 0) {
         NodeRec r;                                                    // Node_V(0), self_play.py:596 / :691
         r.prior = 0.0; r.w = 0.f; r.var = 0.f; r.n = 0; r.pending = 0; r.block = blk; r.action = 0xFFFF; r.flags = 0; r.term = 0;
         arena[0] = r;
-        c.cur = 0; c.free_slot = free_slot; c.need_eval = over ? 0 : 1; c.root_row = row; c.error = blk < 0 ? 1 : 0;
+        c.cur = 0; c.free_slot = free_slot; c.need_eval = over ? 0 : 1; c.root_row = 0; c.error = blk < 0 ? 1 : 0;
         c.finished = over ? 1 : 0;
         if (c.error) atomicAdd(&d.counters[CNT_ERRORS], 1);
         d.ctl[g] = c;
-        if (!over) d.row_game[row] = g;
+        if (!over) d.game_nslot[g] = 1;
     }
 }
 
@@ -131,7 +128,7 @@ __global__ __launch_bounds__(64) void k_expand_roots(EngineDev d) {
     GameCtl* c = &d.ctl[g];
     if (!c->need_eval) return;
     NodeRec* arena = arena_of<S>(d.arena, g, c->cur, d.sc.arena_slots);
-    const int blk = arena[0].block, row = c->root_row;
+    const int blk = arena[0].block, row = d.game_off[g];              // the root was the game's only entry of the batch
     const int nchild = hdr_of<S>(arena, blk)->nchild;
     const float* pol = d.policy + (size_t)row * d.sc.A;
     const float val = d.value[row];
@@ -187,11 +184,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
     const int g = blockIdx.x, lane = lane_id();
     GameCtl* c = &d.ctl[g];
     const SearchCfg& sc = d.sc;
-    if (lane == 0) c->n_paths = 0;
+    __shared__ uint32_t bits_s[(13 * G::P + 31) / 32];
+    if (lane == 0) { c->n_paths = 0; d.game_nslot[g] = 0; d.game_act[g] = 0; }
     if (!c->searching || c->error) return;           // a game in error (arena overflow) is parked, never retried
     NodeRec* arena = arena_of<S>(d.arena, g, c->cur, sc.arena_slots);
     if (arena[0].n >= c->n_target) { if (lane == 0) c->active = 0; return; }
-    if (lane == 0) atomicAdd(&d.counters[CNT_ACTIVE], 1);
+    if (lane == 0) d.game_act[g] = 1;
+    int nslot = 0;                                   // evaluation-batch entries this game has written in this wave
     BoardWave<S> bw; bw.init(&lds);
     WaveRng rng; rng.key = d.rng[g].key; rng.pos = d.rng[g].pos; rng.scratch = mt_scratch; rng.draws = 0;
     int free_slot = c->free_slot;
@@ -285,19 +284,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
                 ++sims;
                 continue;
             }
-            // the evaluation-batch row is requested first: the atomic's round trip hides behind the flood fill below
-            const bool fits = free_slot + HS + G::A <= sc.arena_slots;  // room for the largest possible block: no row is taken in vain
+            const bool fits = free_slot + HS + G::A <= sc.arena_slots;  // room for the largest possible block
             if (!fits) { err |= 1; break; }
-            if (lane == 0) row = atomicAdd(&d.counters[CNT_ROWS], 1);
             bw.load_colors(st.bb[0], st.bb[1]);
             bw.analyze();
             const int blk = make_block(bw, st, arena, free_slot, sc.arena_slots, true);
-            row = __shfl(row, 0);
-            encode_planes(bw, st, d.rules, d.obs + (size_t)row * d.rules.encode_dim * G::P);   // self_play.py:798
+            row = nslot++;                                             // the game's own next slot: no allocation, no atomic
+            encode_bits(bw, st, d.rules, bits_s, d.obs_bits + ((size_t)g * sc.R + row) * d.obs_words);   // self_play.py:798
             if (lane == 0) {
                 arena[node].block = blk;
                 arena[node].flags |= F_PSEUDO;
-                d.row_game[row] = g;
             }
             ++evals;
         }
@@ -309,6 +305,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
         ++npaths;
     }
     if (lane == 0) {
+        d.game_nslot[g] = nslot;
         c->n_paths = npaths; c->free_slot = free_slot; c->error |= err;
         c->sims += sims; c->depth_sum += depth_sum; c->evals += evals; c->tie_draws += rng.draws; c->child_sum += child_sum;
         d.rng[g].pos = rng.pos;
@@ -330,7 +327,7 @@ __global__ __launch_bounds__(64) void k_absorb(EngineDev d) {
     unsigned long long sims = 0;
     for (int q = 0; q < npaths; ++q) {                                 // self_play.py:651-654
         const int* path = paths + q * sc.maxd;
-        const int len = d.path_len[(size_t)g * sc.R + q], row = d.path_row[(size_t)g * sc.R + q];
+        const int len = d.path_len[(size_t)g * sc.R + q], row = d.game_off[g] + d.path_row[(size_t)g * sc.R + q];
         for (int dd = lane; dd < len; dd += 64) arena[path[dd]].pending -= sc.wu;     // self_play.py:772-774
         __syncthreads();
         const int leaf = path[len - 1];
@@ -404,6 +401,7 @@ __global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions
     __shared__ uint32_t bits_s[(13 * G::P + 31) / 32];
     const int g = blockIdx.x, lane = lane_id();
     GameCtl* c = &d.ctl[g];
+    if (lane == 0) d.game_nslot[g] = 0;
     if (c->finished || c->error) { if (lane == 0) { done_out[g] = c->error ? 2 : 1; moves_out[g] = c->moves; } return; }
     const SearchCfg& sc = d.sc;
     NodeRec* old = arena_of<S>(d.arena, g, c->cur, sc.arena_slots);
@@ -488,11 +486,8 @@ __global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions
         child.block = blk; child.term = 0; child.flags &= (uint8_t)~F_PSEUDO;
         if (lane == 0) nw[0] = child;
         if (!done) {
-            int row = 0;
-            if (lane == 0) row = atomicAdd(&d.counters[CNT_ROWS], 1);
-            row = __shfl(row, 0);
-            encode_planes(bw, st, d.rules, d.obs + (size_t)row * d.rules.encode_dim * G::P);
-            if (lane == 0) { c->need_eval = 1; c->root_row = row; d.row_game[row] = g; }
+            encode_bits(bw, st, d.rules, bits_s, d.obs_bits + (size_t)g * sc.R * d.obs_words);     // the game's slot 0
+            if (lane == 0) { c->need_eval = 1; c->root_row = 0; d.game_nslot[g] = 1; }
         }
     }
     if (lane == 0) {
@@ -577,6 +572,46 @@ __global__ __launch_bounds__(64) void k_final(EngineDev d, float* score, float* 
             if (bw.pt[k] < G::P) terr[(size_t)g * G::P + bw.pt[k]] = owner[k] == 1 ? 1.f : owner[k] == 2 ? -1.f : 0.f;
 }
 
+// Float planes [rows][C][P] of the pending batch (what env.encode returns, self_play.py:798), for hosts that evaluate it themselves.
+__global__ __launch_bounds__(256) void k_bits_to_planes(const uint32_t* __restrict__ bits, const int32_t* __restrict__ row_slot,
+                                                        float* __restrict__ out, int rows, int CP, int W) {
+    const size_t total = (size_t)rows * CP;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / CP), k = (int)(i % CP);
+        out[i] = (float)((bits[(size_t)row_slot[r] * W + (k >> 5)] >> (k & 31)) & 1u);
+    }
+}
+
+// Counts -> dense rows: one workgroup scans game_nslot over the games (exclusive prefix = game_off), lists the slots in row order
+// (row_slot) and leaves the totals where the host reads them (CNT_ROWS, CNT_ACTIVE).  4096 games: ~5 us.
+__global__ __launch_bounds__(1024) void k_compact(EngineDev d, int R, int count_active) {
+    __shared__ int part[1024];
+    __shared__ int act_s;
+    const int tid = threadIdx.x, G = d.G;
+    const int per = (G + 1023) / 1024, lo = tid * per, hi = lo + per < G ? lo + per : G;
+    if (tid == 0) act_s = 0;
+    int sum = 0, act = 0;
+    for (int g = lo; g < hi; ++g) { sum += d.game_nslot[g]; if (count_active) act += d.game_act[g]; }
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {                        // inclusive scan over the 1024 partial sums
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    if (act) atomicAdd(&act_s, act);
+    int base = part[tid] - sum;
+    for (int g = lo; g < hi; ++g) {
+        const int n = d.game_nslot[g];
+        d.game_off[g] = base;
+        for (int k = 0; k < n; ++k) d.row_slot[base + k] = g * R + k;
+        base += n;
+    }
+    __syncthreads();
+    if (tid == 0) { d.counters[CNT_ROWS] = part[1023]; if (count_active) d.counters[CNT_ACTIVE] = act_s; }
+}
+
 #define TG_LAUNCH(ctx, kern, grid, ...)                                                                   \
     do {                                                                                                  \
         if ((ctx)->S == 9) hipLaunchKernelGGL(kern<9>, dim3(grid), dim3(64), 0, (ctx)->stream, __VA_ARGS__); \
@@ -658,8 +693,16 @@ int tg_engine_create(tg_ctx* ctx) {
     TG_HIP(ctx, hipMalloc((void**)&e->dev.path_nodes, sizeof(int32_t) * (size_t)G * R * sc.maxd));
     TG_HIP(ctx, hipMalloc((void**)&e->dev.path_len, sizeof(int32_t) * (size_t)G * R));
     TG_HIP(ctx, hipMalloc((void**)&e->dev.path_row, sizeof(int32_t) * (size_t)G * R));
-    TG_HIP(ctx, hipMalloc((void**)&e->dev.row_game, sizeof(int32_t) * (size_t)e->rows_cap));
-    TG_HIP(ctx, hipMalloc((void**)&e->dev.obs, sizeof(float) * (size_t)e->rows_cap * C * P));
+    e->dev.G = G;
+    e->dev.obs_words = (C * P + 31) / 32;
+    TG_HIP(ctx, hipMalloc((void**)&e->dev.obs_bits, sizeof(uint32_t) * (size_t)e->rows_cap * e->dev.obs_words));
+    TG_HIP(ctx, hipMalloc((void**)&e->dev.row_slot, sizeof(int32_t) * (size_t)e->rows_cap));
+    TG_HIP(ctx, hipMalloc((void**)&e->dev.game_nslot, sizeof(int32_t) * (size_t)G));
+    TG_HIP(ctx, hipMalloc((void**)&e->dev.game_off, sizeof(int32_t) * (size_t)G));
+    TG_HIP(ctx, hipMalloc((void**)&e->dev.game_act, (size_t)G));
+    TG_HIP(ctx, hipMemsetAsync(e->dev.game_nslot, 0, sizeof(int32_t) * (size_t)G, ctx->stream));
+    TG_HIP(ctx, hipMemsetAsync(e->dev.game_off, 0, sizeof(int32_t) * (size_t)G, ctx->stream));
+    TG_HIP(ctx, hipMemsetAsync(e->dev.game_act, 0, (size_t)G, ctx->stream));
     TG_HIP(ctx, hipMalloc((void**)&e->dev.policy, sizeof(float) * (size_t)e->rows_cap * A));
     TG_HIP(ctx, hipMalloc((void**)&e->dev.value, sizeof(float) * (size_t)e->rows_cap));
     TG_HIP(ctx, hipMalloc((void**)&e->dev.counters, sizeof(int32_t) * CNT_N));
@@ -675,7 +718,6 @@ int tg_engine_create(tg_ctx* ctx) {
     if (cfg.record_games) {
         // a game has at most max_step moves (step_count starts at 1 and the game ends when it exceeds max_step, go_env.cc:67)
         e->dev.hist_T = cfg.max_step > 0 ? cfg.max_step : 1;
-        e->dev.obs_words = (C * P + 31) / 32;
         const size_t n = (size_t)G * e->dev.hist_T;
         TG_HIP(ctx, hipMalloc((void**)&e->dev.hist_obs, sizeof(uint32_t) * n * e->dev.obs_words));
         TG_HIP(ctx, hipMalloc((void**)&e->dev.hist_cnt, sizeof(int32_t) * n * A));
@@ -691,12 +733,12 @@ int tg_engine_create(tg_ctx* ctx) {
 void tg_engine_destroy(tg_ctx* ctx) {
     Engine* e = ctx->eng;
     if (!e) return;
-    void* ptrs[] = {e->dev.arena, e->dev.ctl, e->dev.rng, e->dev.path_nodes, e->dev.path_len, e->dev.path_row, e->dev.row_game,
-                    e->dev.obs, e->dev.policy, e->dev.value, e->dev.counters, e->d_noise, e->d_i32, e->d_f32, e->d_u8,
+    void* ptrs[] = {e->dev.arena, e->dev.ctl, e->dev.rng, e->dev.path_nodes, e->dev.path_len, e->dev.path_row, e->dev.row_slot,
+                    e->dev.obs_bits, e->dev.game_nslot, e->dev.game_off, e->dev.game_act, e->dev.policy, e->dev.value, e->dev.counters, e->d_noise, e->d_i32, e->d_f32, e->d_u8,
                     e->d_fin, e->dev.hist_obs, e->dev.hist_cnt, e->dev.hist_pl};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (e->h_rng) (void)hipHostFree(e->h_rng);
-    e->hv_obs.release(); e->hv_cnt.release(); e->hv_z.release(); e->hv_own.release(); e->hv_pl.release(); e->hv_game.release();
+    e->obs_f32.release(); e->hv_obs.release(); e->hv_cnt.release(); e->hv_z.release(); e->hv_own.release(); e->hv_pl.release(); e->hv_game.release();
     for (hipEvent_t ev : e->tev) (void)hipEventDestroy(ev);
     tg_net_destroy(ctx);
     delete e;
@@ -723,9 +765,10 @@ int tg_sp_reset(tg_ctx* ctx, const uint32_t* seeds, const uint8_t* mask) {
         TG_HIP(ctx, hipMemcpyAsync(e->d_u8, mask, G, hipMemcpyHostToDevice, ctx->stream));
         d_mask = e->d_u8;
     }
-    zero_counter(ctx, CNT_ROWS);
     if (ctx->S == 9) hipLaunchKernelGGL(k_reset<9>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<9>*)nullptr);
     else hipLaunchKernelGGL(k_reset<19>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<19>*)nullptr);
+    TG_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, ctx->stream, e->dev, e->R, 0);
     TG_HIP(ctx, hipGetLastError());
     e->batch_kind = BATCH_ROOTS; e->batch_ready = false;
     if (!mask) e->all_reset = true;
@@ -747,9 +790,10 @@ int tg_sp_reset_from(tg_ctx* ctx, const void* states, const uint8_t* mask) {
     if (mask) { TG_HIP(ctx, hipMemcpyAsync(e->d_u8, mask, G, hipMemcpyHostToDevice, ctx->stream)); d_mask = e->d_u8; }
     for (int g = 0; g < G; ++g) if (!mask || mask[g]) e->h_moves[g] = 0;
     e->fin_slot.clear(); e->fin_off.clear(); e->fin_positions = 0;
-    zero_counter(ctx, CNT_ROWS);
     if (ctx->S == 9) hipLaunchKernelGGL(k_reset<9>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<9>*)ctx->env_in.p);
     else hipLaunchKernelGGL(k_reset<19>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<19>*)ctx->env_in.p);
+    TG_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, ctx->stream, e->dev, e->R, 0);
     TG_HIP(ctx, hipGetLastError());
     int32_t cnt[CNT_N];
     int rc = read_counters(ctx, cnt);
@@ -785,8 +829,14 @@ int tg_sp_batch_obs(tg_ctx* ctx, float* obs, int32_t n_rows) {
     NEED_ENGINE(ctx);
     Engine* e = ctx->eng;
     if (n_rows < 0 || n_rows > e->rows_cap) return TG_ERR_ARG;
-    size_t per = (size_t)ctx->cfg.encode_dim * ctx->P;
-    TG_HIP(ctx, hipMemcpyAsync(obs, e->dev.obs, sizeof(float) * per * n_rows, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_rows == 0) return TG_OK;
+    const size_t per = (size_t)ctx->cfg.encode_dim * ctx->P;
+    if (e->obs_f32.reserve(sizeof(float) * per * n_rows)) TG_FAIL(ctx, TG_ERR_HIP, "hipMalloc failed");
+    int grid = (int)((per * n_rows + 255) / 256); if (grid > 65535) grid = 65535;
+    hipLaunchKernelGGL(k_bits_to_planes, dim3(grid), dim3(256), 0, ctx->stream, (const uint32_t*)e->dev.obs_bits,
+                       (const int32_t*)e->dev.row_slot, (float*)e->obs_f32.p, (int)n_rows, (int)per, e->dev.obs_words);
+    TG_HIP(ctx, hipGetLastError());
+    TG_HIP(ctx, hipMemcpyAsync(obs, e->obs_f32.p, sizeof(float) * per * n_rows, hipMemcpyDeviceToHost, ctx->stream));
     TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return TG_OK;
 }
@@ -856,10 +906,11 @@ int tg_sp_collect(tg_ctx* ctx, int32_t* n_active, int32_t* n_rows) {
     Engine* e = ctx->eng;
     if (e->batch_kind != BATCH_NONE) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_collect: an evaluation batch is pending");
     { int rc = rng_to_device(ctx); if (rc) return rc; }
-    TG_HIP(ctx, hipMemsetAsync(e->dev.counters, 0, sizeof(int32_t) * 2, ctx->stream));     // CNT_ROWS, CNT_ACTIVE
     const bool timed = e->tprof && e->tev_used + 4 <= e->tev.size();
     if (timed) { TG_HIP(ctx, hipEventRecord(e->tev[e->tev_used], ctx->stream)); }
     TG_LAUNCH(ctx, k_collect, e->G, e->dev);
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, ctx->stream, e->dev, e->R, 1);
+    TG_HIP(ctx, hipGetLastError());
     if (timed) { TG_HIP(ctx, hipEventRecord(e->tev[e->tev_used + 1], ctx->stream)); e->tev_kind[e->tev_used / 2] = 0; e->tev_used += 2; e->tree_waves++; }
     int32_t cnt[CNT_N];
     int rc = read_counters(ctx, cnt);
@@ -967,10 +1018,11 @@ int tg_sp_play(tg_ctx* ctx, const int32_t* actions, uint8_t* done) {
     if (e->batch_kind != BATCH_NONE) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_play: an evaluation batch is pending");
     int32_t* d_act = e->d_i32;
     TG_HIP(ctx, hipMemcpyAsync(d_act, actions, sizeof(int32_t) * G, hipMemcpyHostToDevice, ctx->stream));
-    zero_counter(ctx, CNT_ROWS);
     int32_t* d_moves = e->d_i32 + G;
     std::vector<int32_t> prev = e->h_moves;
     TG_LAUNCH(ctx, k_play, G, e->dev, (const int32_t*)d_act, e->d_u8, d_moves);
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, ctx->stream, e->dev, e->R, 0);
+    TG_HIP(ctx, hipGetLastError());
     TG_HIP(ctx, hipMemcpyAsync(done, e->d_u8, G, hipMemcpyDeviceToHost, ctx->stream));
     TG_HIP(ctx, hipMemcpyAsync(e->h_moves.data(), d_moves, sizeof(int32_t) * G, hipMemcpyDeviceToHost, ctx->stream));
     int32_t cnt[CNT_N];

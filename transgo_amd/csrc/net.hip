@@ -47,6 +47,8 @@ struct Net {
     int dma = 0;                                   // attention-free F=128/256 f32 tower: 1 = k_conv3x3_sg chain (default), 0 = k_conv3x3 (TG_DMA_CONV=0)
     ConvW head; const float* w_vo = nullptr; const float* b_vo = nullptr; const float* w_v = nullptr; const float* b_v = nullptr;
     const float* w_o = nullptr; const float* b_o = nullptr; const float* w_a = nullptr; const float* b_a = nullptr;
+    // engine batches arrive bit-packed and sparse (engine.h: obs_bits through row_slot); tg_net_predict hands float planes
+    const uint32_t* in_bits = nullptr; const int32_t* in_slot = nullptr; int in_words = 0;
     float* x0 = nullptr;   // [rows][P][16] input planes, channel-minor
     float* bufA = nullptr; float* bufB = nullptr; float* bufH = nullptr;   // [rows][P][F]
     float* hc = nullptr;   // [rows][P][16] head conv output
@@ -87,6 +89,21 @@ __global__ __launch_bounds__(256) void k_obs_to_rows(const float* __restrict__ o
     }
 }
 
+
+// The same from the engine's evaluation batch: row r = entry row_slot[r] of the bit-packed batch (bit c*P + p of its W words).
+template <int S>
+__global__ __launch_bounds__(256) void k_bits_to_rows(const uint32_t* __restrict__ bits, const int32_t* __restrict__ row_slot,
+                                                      float* __restrict__ x0, int rows, int C, int W) {
+    constexpr int P = S * S;
+    const size_t total = (size_t)rows * P * 16;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i & 15);
+        const size_t m = i >> 4;
+        const int p = (int)(m % P), k = c * P + p;
+        const size_t r = m / P;
+        x0[i] = c < C ? (float)((bits[(size_t)row_slot[r] * W + (k >> 5)] >> (k & 31)) & 1u) : 0.f;
+    }
+}
 
 // Conv epilogue shared by the conv kernels.  acc[ct][t] holds couts ct*16 + kq*4 .. +3 of row mrow[t].
 // Loads and stores retire through ONE in-order counter (vmcnt), so a load issued after stores waits for all of them: per-cout
@@ -790,6 +807,20 @@ __global__ __launch_bounds__(256) void k_obs_to_rows_h(const float* __restrict__
     }
 }
 
+template <int S>
+__global__ __launch_bounds__(256) void k_bits_to_rows_h(const uint32_t* __restrict__ bits, const int32_t* __restrict__ row_slot,
+                                                        _Float16* __restrict__ x0, int rows, int C, int W) {
+    constexpr int P = S * S;
+    const size_t total = (size_t)rows * P * 64;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i & 63);
+        const size_t m = i >> 6;
+        const int p = (int)(m % P), k = c * P + p;
+        const size_t r = m / P;
+        x0[h16_index((int)m, c, rows * P)] = c < C ? (_Float16)(float)((bits[(size_t)row_slot[r] * W + (k >> 5)] >> (k & 31)) & 1u) : (_Float16)0.f;
+    }
+}
+
 // fp16 head conv (F -> 16 couts: value/ownership and policy convs with their BNs folded, model.py:65-76): out[m][16] = relu(acc +
 // bias) in f32 for k_heads.  One 16-cout tile makes this an LDS-read-bound kernel (one B fragment per MFMA), not an MFMA-bound
 // one: the 9 A fragments of a 32-channel slice live in registers, slabs and the slice's 9-KB weight block are double-buffered
@@ -1185,7 +1216,10 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
     const int grid_f = (M + 64 * NPT - 1) / (64 * NPT);
     const double conv_flops = 2.0 * 9.0 * (double)F * (double)F * (double)M;
     int g0 = (int)(((size_t)M * 16 + 255) / 256); if (g0 > 65535) g0 = 65535;
-    if (n->prec == 0) hipLaunchKernelGGL((k_obs_to_rows<S>), dim3(g0), dim3(256), 0, st, obs, n->x0, rows, n->C);
+    if (n->prec == 0) {
+        if (n->in_bits) hipLaunchKernelGGL((k_bits_to_rows<S>), dim3(g0), dim3(256), 0, st, n->in_bits, n->in_slot, n->x0, rows, n->C, n->in_words);
+        else hipLaunchKernelGGL((k_obs_to_rows<S>), dim3(g0), dim3(256), 0, st, obs, n->x0, rows, n->C);
+    }
     float* x = n->bufA; float* y = n->bufB;
     if constexpr (F == 128 || F == 256) {
         if (n->prec >= 1) {
@@ -1204,7 +1238,8 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
             // stem on the fp16 matrix cores too (input planes are 0/1, exact in fp16; 16 planes padded to 64 channels = 18 stages):
             // writes the f32 residual stream x and the first conv input relu(bn_next(x)) as fp16
             int g0h = (int)(((size_t)M * 64 + 255) / 256); if (g0h > 65535) g0h = 65535;
-            hipLaunchKernelGGL((k_obs_to_rows_h<S>), dim3(g0h), dim3(256), 0, st, obs, n->x0h, rows, n->C);
+            if (n->in_bits) hipLaunchKernelGGL((k_bits_to_rows_h<S>), dim3(g0h), dim3(256), 0, st, n->in_bits, n->in_slot, n->x0h, rows, n->C, n->in_words);
+            else hipLaunchKernelGGL((k_obs_to_rows_h<S>), dim3(g0h), dim3(256), 0, st, obs, n->x0h, rows, n->C);
             if (r16)
                 hipLaunchKernelGGL((k_conv3x3_h2<S, 64, F, 4, true>), dim3(grid_h2), dim3(256), 0, st, (const _Float16*)n->x0h, x, n->act16,
                                    (const float*)nullptr, (const _Float16*)n->stem_h, n->stem.b, nb ? n->blocks[0].s1 : n->s_end,
@@ -1640,7 +1675,11 @@ void tg_net_destroy(tg_ctx* ctx) {
 int tg_net_forward(tg_ctx* ctx, int rows) {
     Engine* e = ctx->eng;
     if (!e || !e->net) TG_FAIL(ctx, TG_ERR_STATE, "no network weights loaded (tg_net_load)");
-    return forward(ctx, e->net, e->dev.obs, rows, e->dev.policy, e->dev.value, nullptr);
+    Net* n = e->net;
+    n->in_bits = e->dev.obs_bits; n->in_slot = e->dev.row_slot; n->in_words = e->dev.obs_words;
+    const int rc = forward(ctx, n, nullptr, rows, e->dev.policy, e->dev.value, nullptr);
+    n->in_bits = nullptr; n->in_slot = nullptr;
+    return rc;
 }
 
 // main_prediction on host buffers (model.py:17-20): obs f32[n][C][S][S] -> policy f32[n][A], value f32[n], own f32[n][P]

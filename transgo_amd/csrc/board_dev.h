@@ -449,25 +449,53 @@ template <int S> __device__ void encode_planes(BoardWave<S>& bw, const BoardStat
 }
 
 // -> the same planes bit-packed: bit i of the plane-major flat index i = c*P + p, little-endian in u32 words
-// (ceil(C*P/32) words; the layout tg_replay_append stores).  `lds` = that many words of LDS scratch.
+// (ceil(C*P/32) words; the layout tg_replay_append stores).  `lds` = that many words of LDS scratch (19x19 form only).
+// 9x9 (the size every headline configuration runs at): no LDS and no atomics -- plane c's bits of the points k*64..k*64+63 are
+// one 64-bit ballot (wave-uniform), and every lane assembles the output words it owns (w = lane, lane + 64, ...) from the ballots
+// that overlap them by shifts.  Other sizes OR the bits into an LDS image with atomics (up to 32 lanes per word: ~4x slower per
+// position, but 19x19 steps are dominated by the tower anyway).
 template <int S> __device__ void encode_bits(BoardWave<S>& bw, const BoardState<S>& st, const RulesCfg& cfg, uint32_t* lds,
                                              uint32_t* out) {
     using G = Geo<S>;
     uint32_t m[G::NW];
     encode_mask(bw, st, cfg, m);
     const int C = cfg.encode_dim, W = (C * G::P + 31) / 32;
-    for (int i = bw.lane; i < W; i += 64) lds[i] = 0;
-    __syncthreads();
+    if constexpr (S == 9) {
+        constexpr int WPL = ((13 * G::P + 31) / 32 + 63) / 64;      // output words per lane
+        uint32_t word[WPL];
 #pragma unroll
-    for (int k = 0; k < G::NW; ++k) {
-        const int p = bw.pt[k];
+        for (int q = 0; q < WPL; ++q) word[q] = 0;
 #pragma unroll
-        for (int c = 0; c < 13; ++c)
-            if (c < C && (m[k] >> c & 1u)) { const int i = c * G::P + p; atomicOr(&lds[i >> 5], 1u << (i & 31)); }
+        for (int c = 0; c < 13; ++c) {
+            if (c < C) {                                            // wave-uniform
+#pragma unroll
+                for (int k = 0; k < G::NW; ++k) {
+                    const uint64_t B = ballot64((m[k] >> c) & 1u);  // bits of plane c for points k*64 .. (invalid points are 0)
+                    const int base = c * G::P + k * 64;             // stream position of B's bit 0
+#pragma unroll
+                    for (int q = 0; q < WPL; ++q) {
+                        const int off = base - 32 * (q * 64 + bw.lane);     // B's bit 0 relative to this lane's word
+                        if (off > -64 && off < 32) word[q] |= off >= 0 ? (uint32_t)(B << off) : (uint32_t)(B >> (-off));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < WPL; ++q) { const int w = q * 64 + bw.lane; if (w < W) out[w] = word[q]; }
+    } else {
+        for (int i = bw.lane; i < W; i += 64) lds[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < G::NW; ++k) {
+            const int p = bw.pt[k];
+#pragma unroll
+            for (int c = 0; c < 13; ++c)
+                if (c < C && (m[k] >> c & 1u)) { const int i = c * G::P + p; atomicOr(&lds[i >> 5], 1u << (i & 31)); }
+        }
+        __syncthreads();
+        for (int i = bw.lane; i < W; i += 64) out[i] = lds[i];
+        __syncthreads();
     }
-    __syncthreads();
-    for (int i = bw.lane; i < W; i += 64) out[i] = lds[i];
-    __syncthreads();
 }
 
 // board.cc:822-958 getTTScore.  Loads colours itself.  Returns raw Tromp-Taylor area difference (0 on an empty board,

@@ -60,8 +60,26 @@ template <int S> struct WaveLds {
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
 
+// 9x9 only: an 81-bit board as two words, and its 4-neighbourhood dilation (bit p = point p, row-major).  A shift by one moves
+// stones across row ends, which the column masks take out again.
+struct B81 { uint64_t lo, hi; };
+__device__ __forceinline__ B81 b81_dilate(B81 g) {
+    constexpr uint64_t C0_LO = 0x8040201008040201ull, C0_HI = 0x100ull;             // x == 0: bits 0, 9, ..., 63 | 72
+    constexpr uint64_t C8_LO = 0x4020100804020100ull, C8_HI = 0x10080ull;           // x == 8: bits 8, 17, ..., 62 | 71, 80
+    B81 r;
+    r.lo = g.lo | (((g.lo >> 1) | (g.hi << 63)) & ~C8_LO) | ((g.lo << 1) & ~C0_LO) | ((g.lo >> 9) | (g.hi << 55)) | (g.lo << 9);
+    r.hi = g.hi | ((g.hi >> 1) & ~C8_HI) | (((g.hi << 1) | (g.lo >> 63)) & ~C0_HI) | (g.hi >> 9) | ((g.hi << 9) | (g.lo >> 55));
+    return r;
+}
+template <int S> struct BoardRegs {};
+template <> struct BoardRegs<9> {
+    uint64_t bq[2][2];      // the bitboards load_colors() was given (wave-uniform)
+    uint16_t lab_r[2];      // label_groups(): label of the own points' groups (kNone if unlabelled)
+    uint16_t lib_r[2];      //                 and their liberty counts
+};
+
 // Everything a lane knows about its NW points.
-template <int S> struct BoardWave {
+template <int S> struct BoardWave : BoardRegs<S> {
     using G = Geo<S>;
     static constexpr int NW = G::NW;
     WaveLds<S>* L;
@@ -98,6 +116,10 @@ template <int S> struct BoardWave {
 
     // colours from bitboards -> registers + LDS
     __device__ __forceinline__ void load_colors(const uint64_t* bbB, const uint64_t* bbW) {
+        if constexpr (S == 9) {
+#pragma unroll
+            for (int k = 0; k < NW; ++k) { this->bq[0][k] = bbB[k]; this->bq[1][k] = bbW[k]; }
+        }
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
             int c = kWall;
@@ -125,6 +147,44 @@ template <int S> struct BoardWave {
     // Connected components by min-label propagation + pointer jumping.  with_empty: empty regions are labelled too
     // (needed for Tromp-Taylor scoring only).  Result in L->lab.
     __device__ void label_groups(bool with_empty) {
+        if constexpr (S == 9) {
+            // Barrier-free: every lane grows the group of each of its own points as an 81-bit board in registers (dilate, mask with
+            // the stones of that colour -- or the empty points -- until no lane's board changes), then label = lowest point of the
+            // group and liberties = empty points its dilation touches.  Same labels and counts as the propagation below.
+            constexpr uint64_t ALL_HI = 0x1FFFFull;
+            const B81 blk{this->bq[0][0], this->bq[0][1]}, wht{this->bq[1][0], this->bq[1][1]};
+            const B81 emp{~(blk.lo | wht.lo), ~(blk.hi | wht.hi) & ALL_HI};
+            B81 g[NW], own[NW];
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                const bool on = (col[k] == kBlack || col[k] == kWhite || (with_empty && col[k] == kEmpty));
+                own[k] = col[k] == kBlack ? blk : col[k] == kWhite ? wht : emp;
+                g[k].lo = (on && k == 0) ? 1ull << lane : 0ull;
+                g[k].hi = (on && k == 1) ? 1ull << lane : 0ull;
+            }
+            for (;;) {
+                bool ch = false;
+#pragma unroll
+                for (int k = 0; k < NW; ++k) {
+                    B81 n = b81_dilate(g[k]);
+                    n.lo &= own[k].lo; n.hi &= own[k].hi;
+                    ch |= (n.lo != g[k].lo) | (n.hi != g[k].hi);
+                    g[k] = n;
+                }
+                if (!__any(ch)) break;                                   // a board only grows and has 81 bits: at most 81 trips
+            }
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                const bool on = (g[k].lo | g[k].hi) != 0;
+                const int lb = g[k].lo ? __ffsll((long long)g[k].lo) - 1 : 63 + __ffsll((long long)g[k].hi);
+                const B81 d = b81_dilate(g[k]);
+                this->lab_r[k] = on ? (uint16_t)lb : (uint16_t)kNone;
+                this->lib_r[k] = (uint16_t)(__popcll(d.lo & emp.lo) + __popcll(d.hi & emp.hi));
+                L->lab[pt[k]] = this->lab_r[k];
+            }
+            __syncthreads();
+            return;
+        }
         uint32_t lab[NW];
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
@@ -165,6 +225,15 @@ template <int S> struct BoardWave {
 
     // Liberties per group label into L->cnt (equivalent observable of Block::liberties, board.h:23).
     __device__ void count_liberties() {
+        if constexpr (S == 9) {                                          // label_groups(false) left every group's count with its lanes
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                L->cnt[pt[k]] = (this->lab_r[k] == (uint16_t)pt[k]) ? (uint32_t)this->lib_r[k] : 0u;
+                L->aux[pt[k]] = 0;
+            }
+            __syncthreads();
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < NW; ++k) { L->cnt[pt[k]] = 0; L->aux[pt[k]] = 0; }
         __syncthreads();

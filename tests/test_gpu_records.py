@@ -200,3 +200,46 @@ def test_actor_loop_two_ranks_rccl():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs 2 GPUs")
     _run_actor_ranks("nccl")
+
+
+@pytest.mark.parametrize("C", [9, 13])
+def test_other_plane_counts_through_the_engine(C):
+    """encode9 / encode13 (board_feature.cc:225-253) through the ENGINE's bit-packed paths -- root observation, evaluation batch,
+    per-move record, harvest -- against the oracle environment replaying the same moves (the 10-plane default is covered by every
+    other test; the rules fixtures cover the plane variants only through GoEnv.encode)."""
+    from oracle.go_oracle import OracleGoEnv
+    from transgo_amd.engine import SelfPlayEngine
+    G, moves = 5, 10
+    seen = []
+
+    def ev(obs):
+        seen.append(np.asarray(obs).copy())
+        return evaluators.sharp(obs)
+    eng = SelfPlayEngine(G, num_simulation=24, max_step=moves, encode_dim=C, evaluator=ev)
+    env = OracleGoEnv(max_step=moves, encode_dim=C)
+    seeds = np.arange(70, 70 + G).astype(np.uint32)
+    eng.reset(seeds)
+    states = [env.reset()[0] for _ in range(G)]
+    roots = [[] for _ in range(G)]
+    for m in range(moves):
+        eng.search()
+        vis, rn, pl, st, ob = eng.root_info()
+        assert ob.shape == (G, C, 9, 9)
+        for g in range(G):
+            want = env.encode(states[g])
+            assert np.array_equal(ob[g], want), (C, m, g)
+            roots[g].append(want)
+        acts, _ = eng.choose_moves(vis, st)
+        done = eng.play(acts)
+        states = [env.step(states[g], int(acts[g]))[0] for g in range(G)]
+    assert done.all() and not eng.game_errors().any()
+    h = eng.harvest(device=False, seeds=seeds)
+    assert h.n_games == G and h.n_positions == G * moves
+    obs = h.observations().reshape(G, moves, C, 9, 9)
+    for i, g in enumerate(h.view("slot")):
+        assert np.array_equal(obs[i], np.stack(roots[int(g)]))
+    # every batch the evaluator saw is a stack of legal C-plane encodings: planes are 0/1 and stones never overlap
+    for b in seen:
+        assert b.shape[1] == C and set(np.unique(b)) <= {0.0, 1.0}
+        assert (b[:, 0:3].sum(1) + b[:, 3:6].sum(1)).max() <= 1.0
+    eng.close()

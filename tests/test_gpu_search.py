@@ -228,3 +228,32 @@ def test_peaked_policy_full_games_stay_inside_the_default_arena():
     st2 = sp2.engine.stats()
     print("quarter arena: high-water", st2["max_slots"], "truncated blocks", st2["truncated_blocks"])
     assert st2["errors"] == 0 and sp2.games_dropped == 0
+
+
+def test_wp_mcts_mirror_follows_the_oracle_call_by_call():
+    """transgo_amd.self_play.WP_MCTS -- the reference's per-game object (self_play.py:575-881) over one engine slot: the same
+    calls in the same order (get_action_probs with and without self-play noise, update_with_action, select_action on a given
+    position, then searching on) return the oracle's actions, pis and root observations, with one MT19937 stream per object."""
+    from oracle.go_oracle import OracleGoEnv
+    from oracle.wp_mcts import OracleSearch
+    from transgo_amd.configure import Config
+    from transgo_amd.self_play import WP_MCTS
+    cfg = Config(num_simulation=48, max_step=40)
+    seed = 321
+    m = WP_MCTS(cfg, evaluator=evaluators.sharp, seed=seed)
+    o = OracleSearch(OracleGoEnv(max_step=40), evaluators.sharp, np.random.RandomState(seed), num_simulation=48)
+    assert str(m) == "WP_MCTS"
+    for ply in range(7):
+        selfplay = ply < 4
+        a, pi, obs = m.get_action_probs(is_selfplay=selfplay)
+        oa, opi, oobs, info = o.search_move(selfplay=selfplay)
+        assert a == oa and np.array_equal(pi, opi) and np.array_equal(obs, oobs), ply
+        assert m.root.visit_count(a) == (o.root.kids[a].n if a in o.root.kids else 0)
+        assert m.update_with_action(a) == o.advance(oa)
+    # select_action: fresh tree at the current position, no root noise, temperature 0.12 (self_play.py:689-703) ...
+    assert m.select_action(m.root.state) == o.select_action(o.root.state)
+    # ... and the object keeps searching from that tree with the same stream
+    a, pi, obs = m.get_action_probs(is_selfplay=False)
+    oa, opi, oobs, _ = o.search_move(selfplay=False)
+    assert a == oa and np.array_equal(pi, opi) and np.array_equal(obs, oobs)
+    m.close()

@@ -373,3 +373,16 @@ def test_weight_refresh_is_keyed_on_train_steps_and_content():
     sp2._train_steps_seen, sp2._blob_digest = None, None
     sp2.worker = sp.worker
     assert sp2._fetch_blob(Bare()) is not None and sp2._fetch_blob(Bare()) is None
+
+
+def test_wp_mcts_mirror_has_the_reference_call_surface():
+    """self_play.py:577, :595, :657, :689, :857, :874 -- names, argument names and defaults (construction needs a GPU; the behaviour is
+    checked against the oracle in tests/test_gpu_search.py)."""
+    import inspect
+    from transgo_amd.self_play import WP_MCTS
+    sig = lambda f: [(p.name, p.default) for p in inspect.signature(f).parameters.values()][1:]
+    assert sig(WP_MCTS.__init__)[:4] == [("config", inspect._empty), ("env", None), ("model", None), ("sub_model", None)]
+    assert sig(WP_MCTS.reset_root) == []
+    assert sig(WP_MCTS.get_action_probs) == [("is_selfplay", True), ("now_train_step", 0)]
+    assert sig(WP_MCTS.select_action) == [("gamestate", inspect._empty)]
+    assert sig(WP_MCTS.update_with_action) == [("fall_action", inspect._empty)]

@@ -509,60 +509,55 @@ __device__ __forceinline__ void vmcnt_uniform(int n) {
     else if constexpr (N > 0) vmcnt_uniform<N - 1>(n);
 }
 
-template <int F, int CT, int NPT, int EPI, bool R16 = false>
-__device__ __forceinline__ void conv_epilogue_h(f32x4 (&acc)[CT][NPT], const int (&mrow)[NPT], int M, int co_base, int kq,
-                                                float* __restrict__ out32, _Float16* __restrict__ out16,
-                                                const float* __restrict__ res, const float* par, int pstride) {
-    // par: bias | s2 | t2 of THIS workgroup's couts (co_base .. ), sections pstride floats apart
-    constexpr int CH = 4, NCH = (CT / CH) * NPT;
-    static_assert(CT % CH == 0, "chunking");
-    f32x4 r[2][CH];
-    auto load_res = [&](int c, f32x4* dst) {
-        const int t = c / (CT / CH), h = c % (CT / CH);
-        if (mrow[t] < M) {
+// Epilogue of k_conv3x3_h2 in the PAIRED cout mapping: the weights are restaged (k_restage_half, pair8) so that row i of A tile ct
+// is physical cout (ct >> 1) * 32 + (i >> 2) * 8 + (ct & 1) * 4 + (i & 3); lane kq then holds, across the tile pair (2u, 2u + 1),
+// the 8 CONSECUTIVE couts u * 32 + kq * 8 .. + 7 of its row -- one whole 16-B chunk of the chunk-major fp16 tensors.  Every fp16
+// access of the epilogue (and the fp16 residual read that starts the accumulators) is one 16-B access per lane instead of two
+// 8-B ones: half the memory instructions on the path that the DMA pieces already load.
+template <int F, int CT, int NPT, int EPI, bool R16>
+__device__ __forceinline__ void conv_epilogue_h8(f32x4 (&acc)[CT][NPT], const int (&mrow)[NPT], int M, int co_base, int kq,
+                                                 float* __restrict__ out32, _Float16* __restrict__ out16, const float* par, int pstride) {
+    static_assert(CT % 2 == 0, "tile pairs");
 #pragma unroll
-            for (int i = 0; i < CH; ++i)
-                dst[i] = *(reinterpret_cast<const f32x4*>(res + (size_t)mrow[t] * F + co_base + (h * CH + i) * 16 + kq * 4));
-        }
-    };
-    if (EPI == 1) load_res(0, r[0]);
+    for (int t = 0; t < NPT; ++t) {
+        if (mrow[t] >= M) continue;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int t = c / (CT / CH), h = c % (CT / CH);
-        if (EPI == 1 && c + 1 < NCH) load_res(c + 1, r[(c + 1) & 1]);
-        if (mrow[t] < M) {
+        for (int u = 0; u < CT / 2; ++u) {
+            const int lc = u * 32 + kq * 8, col = co_base + lc;
+            f32x4 v[2];
 #pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const int lc = (h * CH + i) * 16 + kq * 4, col = co_base + lc;
-                f32x4 v = acc[h * CH + i][t] + *reinterpret_cast<const f32x4*>(par + lc);
-                h4 u;
-                if (EPI == 0) {
+            for (int h = 0; h < 2; ++h) v[h] = acc[2 * u + h][t] + *reinterpret_cast<const f32x4*>(par + lc + 4 * h);
+            h8 o;
+            if (EPI == 0) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) u[e] = (_Float16)(v[e] > 0.f ? v[e] : 0.f);
-                    *reinterpret_cast<h4*>(out16 + h16_index(mrow[t], col, M)) = u;
-                } else {
-                    if (EPI == 1) v = v + r[c & 1][i];
-                    if (EPI == 4) {
+                for (int e = 0; e < 8; ++e) { const float w = v[e >> 2][e & 3]; o[e] = (_Float16)(w > 0.f ? w : 0.f); }
+                *reinterpret_cast<h8*>(out16 + h16_index(mrow[t], col, M)) = o;
+            } else {
+                if (EPI == 4) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[h][e] = v[h][e] > 0.f ? v[h][e] : 0.f;
+                }
+                if (out32) {                                             // null: the last block (only its activation feeds the head)
+                    if (R16) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e >> 2][e & 3];
+                        *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(out32) + h16_index(mrow[t], col, M)) = o;
+                    } else {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) *reinterpret_cast<f32x4*>(out32 + (size_t)mrow[t] * F + col + 4 * h) = v[h];
                     }
-                    if (out32) {                                         // null: the last block (only its activation feeds the head)
-                        if (R16) {                                       // fp16 residual stream (net_precision 2), slice-major like the activations
-                            h4 xr;
+                }
+                if (out16) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) xr[e] = (_Float16)v[e];
-                            *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(out32) + h16_index(mrow[t], col, M)) = xr;
-                        } else {
-                            *reinterpret_cast<f32x4*>(out32 + (size_t)mrow[t] * F + col) = v;
-                        }
-                    }
-                    if (out16) {
-                        const f32x4 sc = *reinterpret_cast<const f32x4*>(par + pstride + lc);
-                        const f32x4 sh = *reinterpret_cast<const f32x4*>(par + 2 * pstride + lc);
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(par + pstride + lc + 4 * h);
+                        const f32x4 sh = *reinterpret_cast<const f32x4*>(par + 2 * pstride + lc + 4 * h);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { const float w = v[e] * sc[e] + sh[e]; u[e] = (_Float16)(w > 0.f ? w : 0.f); }
-                        *reinterpret_cast<h4*>(out16 + h16_index(mrow[t], col, M)) = u;
+                        for (int e = 0; e < 4; ++e) { const float w = v[h][e] * sc[e] + sh[e]; o[4 * h + e] = (_Float16)(w > 0.f ? w : 0.f); }
                     }
+                    *reinterpret_cast<h8*>(out16 + h16_index(mrow[t], col, M)) = o;
                 }
             }
         }
@@ -683,17 +678,20 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
             const int m = m0 + (wave * NPT + t) * 16 + j;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!(EPI == 1 && R16 && ct % 2 == 1)) acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};   // (set by its pair's load)
                 if (EPI == 1) {
                     // always issued (rows past the batch re-read the last row and are never stored): the number of residual loads in
-                    // flight must be the same for every wave, because the wait below counts them
+                    // flight must be the same for every wave, because the wait below counts them.  Paired cout mapping (see
+                    // conv_epilogue_h8): one 16-B load covers this lane's 8 couts of the tile pair.
                     const int mc = m < M ? m : M - 1;
                     if (R16) {
-                        const h4 rh = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(res) + h16_index(mc, co0 + ct * 16 + kq * 4, M));
+                        if (ct % 2 == 0) {
+                            const h8 rh = *reinterpret_cast<const h8*>(reinterpret_cast<const _Float16*>(res) + h16_index(mc, co0 + (ct >> 1) * 32 + kq * 8, M));
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[ct][t][e] = (float)rh[e];
+                            for (int e = 0; e < 4; ++e) { acc[ct][t][e] = (float)rh[e]; acc[ct + 1][t][e] = (float)rh[4 + e]; }
+                        }
                     } else {
-                        acc[ct][t] = *reinterpret_cast<const f32x4*>(res + (size_t)mc * F + co0 + ct * 16 + kq * 4);
+                        acc[ct][t] = *reinterpret_cast<const f32x4*>(res + (size_t)mc * F + co0 + (ct >> 1) * 32 + kq * 8 + (ct & 1) * 4);
                     }
                 }
             }
@@ -705,7 +703,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
         // MFMA -- the 0.34-0.68 GB residual read no longer sits in front of the whole tile.
         if (EPI != 1 && first && NSL > 1) vmcnt_uniform<NXQ + 2 * WPW>((NXP - wave * NXQ < 0 ? 0 : NXP - wave * NXQ > NXQ ? NXQ : NXP - wave * NXQ) + 2 * WPW);
         else if (EPI != 1 && first) TG_VMCNT(2 * WPW);
-        else if (EPI == 1) TG_VMCNT(CT * NPT);
+        else if (EPI == 1) TG_VMCNT(R16 ? CT / 2 * NPT : CT * NPT);
         else TG_VMCNT(0);
         first = false;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -760,7 +758,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
         while (nb < nblk && tile_m0(nb) >= M) nb += gridDim.x;
         const bool have_next = nb < nblk;
         if (have_next) { bid = nb; m0 = tile_m0(nb); prologue(); }
-        conv_epilogue_h<F, CT, NPT, (EPI == 1 ? 2 : EPI), R16>(acc, mrow, M, co0, kq, out32, out16, res, par, NCO);   // EPI 4: the stem
+        conv_epilogue_h8<F, CT, NPT, (EPI == 1 ? 2 : EPI), R16>(acc, mrow, M, co0, kq, out32, out16, par, NCO);   // EPI 4: the stem
         if (!have_next) break;
     }
 }
@@ -768,15 +766,17 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
 // stage-ordered fp16 copy of a conv: dst[(slice*9 + tap)][cout][KC] = half(w[tap][cout][slice*KC + c]) for c < cin_src, else 0
 // (w is [9][COUT][cin_src]; the destination covers cin_dst >= cin_src channels: the stem pads its 16 input planes to 64)
 __global__ __launch_bounds__(256) void k_restage_half(const float* __restrict__ w, _Float16* __restrict__ dst, int COUT, int cin_src,
-                                                      int cin_dst, int KC) {
+                                                      int cin_dst, int KC, int pair8) {
     const size_t total = (size_t)9 * COUT * cin_dst;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % KC);
         const size_t r = i / KC;
-        const int co = (int)(r % COUT);
+        int co = (int)(r % COUT);
         const int st = (int)(r / COUT);
         const int sl = st / 9, tap = st % 9;
         const int ci = sl * KC + c;
+        // pair8 (k_conv3x3_h2): destination row r of a 32-row group holds physical cout ((r & 15) >> 2) * 8 + ((r >> 4) & 1) * 4 + (r & 3)
+        if (pair8) co = (co & ~31) | ((((co & 15) >> 2) << 3) + (((co >> 4) & 1) << 2) + (co & 3));
         dst[i] = ci < cin_src ? (_Float16)w[((size_t)tap * COUT + co) * cin_src + ci] : (_Float16)0.f;
     }
 }
@@ -1495,11 +1495,11 @@ int fill_weight_set(tg_ctx* ctx, Net* n, int k, const float* blob, hipStream_t s
     if (n->prec >= 1) {
         // stage-ordered fp16 copies, converted on the device from the blob just uploaded (round to nearest even)
         for (const BlockW& b : view.blocks) {
-            hipLaunchKernelGGL(k_restage_half, dim3(1024), dim3(256), 0, st, b.c1.w, const_cast<_Float16*>(b.h1), F, F, F, 32);   // k_conv3x3_h2: 32-channel stages
-            hipLaunchKernelGGL(k_restage_half, dim3(1024), dim3(256), 0, st, b.c2.w, const_cast<_Float16*>(b.h2), F, F, F, 32);
+            hipLaunchKernelGGL(k_restage_half, dim3(1024), dim3(256), 0, st, b.c1.w, const_cast<_Float16*>(b.h1), F, F, F, 32, 1);   // k_conv3x3_h2: 32-channel stages, paired couts
+            hipLaunchKernelGGL(k_restage_half, dim3(1024), dim3(256), 0, st, b.c2.w, const_cast<_Float16*>(b.h2), F, F, F, 32, 1);
         }
-        hipLaunchKernelGGL(k_restage_half, dim3(256), dim3(256), 0, st, view.stem.w, view.stem_h, F, 16, 64, 32);
-        hipLaunchKernelGGL(k_restage_half, dim3(256), dim3(256), 0, st, view.head.w, view.head_h, 16, F, F, 32);
+        hipLaunchKernelGGL(k_restage_half, dim3(256), dim3(256), 0, st, view.stem.w, view.stem_h, F, 16, 64, 32, 1);
+        hipLaunchKernelGGL(k_restage_half, dim3(256), dim3(256), 0, st, view.head.w, view.head_h, 16, F, F, 32, 0);
         TG_HIP(ctx, hipGetLastError());
     } else if (n->dma) {
         // stage-ordered copy for k_conv3x3_sg, [slice*9 + tap][cout][16 channels of the slice], made on the device

@@ -4,9 +4,9 @@
 // go_env.cc; cited per function).  The mechanism is different by design: the reference keeps incremental liberty
 // counts on linked lists of stones (board.cc:217-428, AoS, 1188 B per state); here a state is two bitboards plus 16 B
 // of scalars (48 B at 9x9, 112 B at 19x19), lanes own points (point p = slot*64 + lane), groups are found by min-label
-// propagation with pointer jumping through LDS, and liberties are counted with LDS atomics, so every per-point answer
-// (legal, suicide, liberty class, eye, alive) is a lane-local read of LDS tables.  New bitboards come straight out of
-// 64-bit ballots.
+// propagation with pointer jumping through LDS and liberties are counted with LDS atomics (at 9x9: by growing each point's
+// group as an 81-bit board in registers, label_groups()), so every per-point answer (legal, suicide, liberty class, eye,
+// alive) is a lane-local read of LDS tables.  New bitboards come straight out of 64-bit ballots.
 //
 // A workgroup is exactly one wavefront (64 threads): __syncthreads() is then a single-wave s_barrier that orders the
 // LDS traffic between lanes at negligible cost, and games never wait for each other's flood-fill trip counts.

@@ -17,7 +17,7 @@ def load(d):
 out = {"source": "rocprofv3 --kernel-trace --pmc ... (separate passes: SQ counters, FETCH_SIZE, WRITE_SIZE) on `python3 bench.py --filters 256 "
                  "--blocks 4 --games 2048 --sims 32 --steps 1 --warmup 1 --stagger 0 --no-cpu-baseline --dtype f16|f16r` (9x9, 8192-leaf "
                  "launches, M = 663552 rows); medians over the full-batch launches of k_conv3x3_h2<9,256,256,EPI>; final round-2 build "
-                 "(chunk-major fp16 activations, counted residual wait)",
+                 "(chunk-major fp16 activations, counted residual wait, paired cout mapping)",
        "correction": "FETCH_SIZE doubled (gfx950: MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact; unit KB.  MFMA pipe busy = "
                      "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs), the round-1 convention", "modes": {}}
 M, F = 8192 * 81, 256

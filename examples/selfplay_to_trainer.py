@@ -13,13 +13,11 @@ tower's state_dict layout; its weights go back into the engine through the same 
 import os
 import sys
 
-import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from transgo_amd import model                                    # noqa: E402
 from transgo_amd.configure import Config                         # noqa: E402
 from transgo_amd.replay_buffer import DeviceReplayMemory         # noqa: E402
 from transgo_amd.self_play import BatchedSelfPlay                # noqa: E402

@@ -2,7 +2,6 @@
 generation (self_play.py:929-967), the device -> device append into the replay store, the multi-rank actor loop -- against the
 same material assembled on the host the way the reference's self-play loop does (self_play.py:917-926: append root observation,
 pi and player per move; :932-940 score, winner, territory at the end)."""
-import os
 import socket
 
 import numpy as np

@@ -183,3 +183,34 @@ def test_example_selfplay_to_trainer_runs():
     spec.loader.exec_module(mod)
     losses = mod.main(games=16, sims=16, max_step=8, batch=64, steps=3)
     assert len(losses) == 3 and all(np.isfinite(losses))
+
+
+def test_staggered_start_spreads_game_ends_without_changing_games():
+    """BatchedSelfPlay.start(stagger=T): slot g sits parked until step g mod T, so a generation's games end spread over T steps; a
+    delayed game is the SAME game (same seed -> same record as in an unstaggered run)."""
+    from transgo_amd.configure import Config
+    from transgo_amd.self_play import BatchedSelfPlay
+    G, T = 12, 6
+    cfg = Config(num_simulation=16, max_step=T)
+    seed_fn = lambda g, k: 5000 + 100 * g + k
+    ref = BatchedSelfPlay(cfg, G, evaluator=evaluators.sharp, seed_fn=seed_fn)
+    first = {}
+    for _ in range(T):
+        for r in ref.step():
+            first[r.seed] = r
+    assert len(first) == G                                            # unstaggered: all twelve end on step T
+    sp = BatchedSelfPlay(cfg, G, evaluator=evaluators.sharp, seed_fn=seed_fn)
+    sp.start(stagger=T)
+    per_step, got = [], {}
+    for _ in range(3 * T):
+        recs = sp.step()
+        per_step.append(len(recs))
+        for r in recs:
+            got.setdefault(r.seed, r)
+    assert per_step[:T - 1] == [0] * (T - 1) and per_step[T - 1:] == [G // T] * (2 * T + 1)      # two games end on every step
+    assert sp.engine.stats()["errors"] == 0 and sp.games_dropped == 0
+    for seed, r in first.items():                                     # first-generation games: identical records
+        q = got[seed]
+        assert q.winner == r.winner and q.players == r.players
+        assert all(np.array_equal(a, b) for a, b in zip(q.visits, r.visits))
+        assert all(np.array_equal(a, b) for a, b in zip(q.observations, r.observations))

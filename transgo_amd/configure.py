@@ -22,6 +22,8 @@ class Config:
         self.num_blocks = 6                      # tower depth (BASELINE.json "N-block x F-filter")
         self.network = "tower"                   # "tower" | "transgo" (the shipped MainNetwork with attention, model.py:49-76)
         self.concurrent_games = 4096             # boards resident on one GPU
+        self.stagger_games = 0                   # T > 1: slot g starts its first game at step g mod T (BatchedSelfPlay.start): games end
+                                                 # spread over T steps instead of all on one; 0 = all slots start together
         self.inference_dtype = "f32"             # "f16": fp16 weights/activations, f32 accumulate (BASELINE config 5; towers of 128/256
                                                  # filters); "f16r": the residual stream in fp16 as well (+4-6 %, error < 4e-4 over 40 blocks)
         self.batch_size = 2048

@@ -101,6 +101,7 @@ class BatchedSelfPlay:
         self.games_dropped = 0                             # games abandoned because their tree outgrew the arena
         self.phase_s = {}
         self._started = False
+        self._parked = None                                # slots waiting for their staggered first move (start(stagger))
 
     def seed_of(self, g):
         k = int(self.games_started[g])
@@ -134,16 +135,39 @@ class BatchedSelfPlay:
             self.games_started[g] += 1
         self.engine.reset(self.seeds, mask)
 
-    def start(self):
-        self._reset(None)
+    def start(self, stagger=0):
+        """stagger = T > 1: slot g plays its first move at step g mod T and is parked until then, so that games end spread over T
+        consecutive steps instead of all on the same one (with a ply limit every game of a generation has the same length) -- a
+        steady flow of finished games to the replay store from the first generation on, paid with a partly idle engine during the
+        first T steps.  No position is played differently: a delayed game is the same game.  (The reference's actors drift apart by
+        themselves, one game per process.)"""
+        T = int(stagger or 0)
+        if T > 1 and self.G > 1:
+            self._start_at = np.arange(self.G) % T
+            self._step_no = 0
+            self._parked = np.ones(self.G, bool)
+            eng = self.engine
+            eng.reset(np.zeros(self.G, np.uint32))                      # brings the engine up (reset_from needs seeded streams) ...
+            eng.reset_from(np.zeros((self.G, eng.ctx.state_size), np.uint8), np.zeros(self.G, bool))     # ... then every slot is parked
+        else:
+            self._reset(None)
         self._started = True
+
+    def _begin_due(self):
+        due = self._parked & (self._start_at == self._step_no)
+        if due.any():
+            self._reset(due)
+            self._parked &= ~due
+        self._step_no += 1
 
     def advance(self, selfplay=True, device=False, num_simulation=0):
         """One move of every game: get_action_probs + update_with_action (self_play.py:917-926).  Returns the games this
         move finished as a `records.Harvest` (None if none did); their slots are restarted with fresh seeds, and so are slots
         whose tree outgrew its arena (counted in games_dropped)."""
         if not self._started:
-            self.start()
+            self.start(getattr(self.config, "stagger_games", 0))
+        if self._parked is not None and self._parked.any():
+            self._begin_due()
         eng = self.engine
         live = int((~eng.finished).sum())
         t0 = time.perf_counter()
@@ -156,6 +180,8 @@ class BatchedSelfPlay:
         t3 = time.perf_counter()
         self.moves_played += live
         h = None
+        if self._parked is not None:
+            done = done & ~self._parked                                 # a parked slot reports "over" without having played
         if done.any():
             h = eng.harvest(device=device, seeds=self.seeds)
             self.games_finished += h.n_games

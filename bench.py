@@ -25,6 +25,9 @@ import time
 
 import numpy as np
 
+# the hosts of this pool share GPU memory between processes through dmabuf handles only (RCCL needs it for N > 1)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

@@ -2,16 +2,23 @@
 """bench.py -- MCTS simulations/sec of the batched self-play hot path on N MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
+        N > 1 and no RANK/WORLD_SIZE in the environment: this process becomes a GPU-free LAUNCHER (as the reference's driver
+        spawns its own workers, transgo.py:92-107): it times the CPU baseline, starts N fresh child processes (one rank per GPU,
+        RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), forwards rank 0's JSON line and exits non-zero if any rank fails.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+        (ranks started by somebody else: rank 0 times the CPU baseline before it touches the GPU, the others wait in
+        init_process_group)
 
 Workload (BASELINE.json configs[1]): 9x9 Go, 400 simulations/move, 6-block x 128-filter tower (random-init weights),
-4096 concurrent boards per GPU, self-play from empty boards with Dirichlet root noise; game seeds 1000*rank + g.
+4096 concurrent boards per GPU, self-play from empty boards with Dirichlet root noise; the k-th game in slot g of rank r is
+seeded (k*world + r)*G + g (transgo_amd.self_play.default_seed: disjoint streams for every game of a job; BASELINE.md 4's
+1000*rank + g would collide from 1000 boards per rank on and is knowingly not followed -- the line says so in config.seeds).
 A step = one move of every board: root noise, ~100 search waves (tree kernels + network forward on each leaf batch),
 visit counts -> pi and sampled move on the host, the move's record entry + re-rooting on the device, and for the games that
 move finished: scoring + target generation on the device (tg_sp_harvest), the gather to rank 0 (RCCL, device buffers) and
 the append into the device-resident replay store (tg_replay_append_dev), then the restart of their slots.
 The boards are staggered before the warm-up (slot g is g mod max_step plies into its game, reached by real self-play with
-16-simulation searches), so the timed steps see the steady state of a running pipeline: ~G/max_step games finish on every
+16-simulation searches; the games the timed steps finish therefore played their early plies under those cheap searches), so the timed steps see the steady state of a running pipeline: ~G/max_step games finish on every
 step.  Boards live in HBM throughout; per step the host receives G*(A+1) int32 visit counts and sends G actions.
 `value` = completed simulations (root visit increments) of all ranks / max-over-ranks wall time; `games_per_hour` =
 games finished (and stored) inside the timed region / the same wall time.
@@ -139,9 +146,9 @@ def kernel_name(S, filters, dtype):
 
 
 def stagger(sp, period, sims=16):
-    """Put slot g exactly (g mod period) plies into its game by real self-play with cheap searches: `period - 1` untimed moves
-    of every board, slot g restarted (fresh seed, empty board, empty record) just before the move that leaves it at its
-    offset.  Every record entry the timed steps later harvest was written by the engine's own tg_sp_play."""
+    """Put slot g (g mod period) plies into its game -- slots with g mod period = 0 are never restarted and end up period - 1
+    plies in -- by real self-play with cheap searches: `period - 1` untimed moves of every board, slot g restarted (fresh seed,
+    empty board, empty record) just before the move that leaves it at its offset.  Every record entry the timed steps later harvest was written by the engine's own tg_sp_play."""
     T0 = period - 1
     offs = np.arange(sp.G) % period
     for s_ in range(T0):
@@ -151,7 +158,7 @@ def stagger(sp, period, sims=16):
         sp.advance(num_simulation=sims)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
@@ -162,40 +169,159 @@ def main():
     ap.add_argument("--blocks", type=int, default=6)
     ap.add_argument("--board", type=int, default=9, help="board edge (9 = BASELINE configs[1]; 19 = configs[3])")
     ap.add_argument("--max-step", type=int, default=0, help="ply limit (default 120 at 9x9, 450 at 19x19)")
-    ap.add_argument("--dtype", choices=["f32", "f16", "f16r"], default="f32",
-                    help="network arithmetic: f32 (BASELINE metric, parity 1e-3) or f16 storage + f32 accumulate (configs[4])")
+    ap.add_argument("--dtype", choices=["f32", "f16", "f16r", "f32x3"], default="f32",
+                    help="network arithmetic: f32 (BASELINE metric, exact-fp32 MFMA), f16 / f16r = fp16 storage + f32 accumulate "
+                         "(configs[4]; f16r: fp16 residual stream too), f32x3 = opt-in split-precision F->F convs (three fp16 MFMA "
+                         "passes over hi/lo halves, f32 accumulate; ~1e-6 of f32)")
     ap.add_argument("--network", choices=["tower", "transgo"], default="tower",
                     help="tower = BASELINE.json's N-block x F-filter net; transgo = the reference's shipped MainNetwork (model.py:41-114)")
     ap.add_argument("--stagger", type=int, default=-1,
                     help="spread the boards over this many ply offsets before the warm-up (default: max_step at 9x9, 0 = all "
                          "boards start together, at 19x19)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=60.0, help="window of each CPU-baseline leg (BASELINE.md 4: 60 s)")
-    a = ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=0.0,
+                    help="window of each CPU-baseline leg (default: 60 s at N = 1 as BASELINE.md 4 says, 30 s at N > 1)")
+    ap.add_argument("--cpu-json", default="", help="(set by the launcher) file holding the CPU-baseline legs the launcher timed")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0, help="launcher: seconds before the ranks are given up on")
+    return ap.parse_args(argv)
+
+
+def cpu_legs(a):
+    """The two CPU-baseline legs (C2's net for the like-for-like ratio, C1 = the plumbing config beside it), run where no GPU
+    context exists: the launcher, or rank 0 before it touches the GPU."""
+    if a.no_cpu_baseline or a.board != 9 or a.network != "tower":
+        return None, None
+    secs = a.cpu_seconds if a.cpu_seconds > 0 else (60.0 if a.gpus <= 1 else 30.0)
+    c2 = cpu_baseline(secs, a.sims, a.filters, a.blocks,
+                      label="C2 net" if (a.sims, a.filters, a.blocks) == (400, 128, 6) else "bench net")
+    c1 = cpu_baseline(secs, 64, 32, 2, label="C1")
+    return c2, c1
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launcher(a, argv):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: the GPU-free parent (nothing here imports torch or touches
+    HIP).  CPU legs first, then N fresh children -- this same file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set -- whose
+    rank 0 prints the JSON line with the CPU legs merged in.  Any failing rank, or the join timeout, ends the others (exact
+    PIDs) and the launcher exits non-zero."""
+    import subprocess
+    import tempfile
+    cpu, cpu_c1 = cpu_legs(a)
+    tmp = tempfile.mkdtemp(prefix="transgo_bench_")
+    cpu_json = os.path.join(tmp, "cpu.json")
+    with open(cpu_json, "w") as f:
+        json.dump({"cpu_baseline": cpu, "cpu_baseline_c1": cpu_c1}, f)
+    port = int(os.environ.get("MASTER_PORT", 0)) or _free_port()
+    args = [x for x in argv] + ["--no-cpu-baseline", "--cpu-json", cpu_json]
+    procs, outs = [], []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(port),
+                   TRANSGO_BENCH_LAUNCHER="bench.py")
+        out = open(os.path.join(tmp, f"rank{r}.out"), "w+")
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + args, env=env, stdout=out, stderr=None))
+    deadline = time.time() + a.launch_timeout
+    rc = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                rc = bad[0][1] if bad[0][1] > 0 else 1
+                print(f"bench.py launcher: rank {bad[0][0]} exited with {bad[0][1]}; stopping the other ranks", file=sys.stderr)
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                rc = 124
+                print(f"bench.py launcher: ranks still running after {a.launch_timeout:.0f} s; giving up", file=sys.stderr)
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    for r, out in enumerate(outs):
+        out.seek(0)
+        txt = out.read()
+        out.close()
+        if r == 0:
+            sys.stdout.write(txt)
+        elif txt.strip():
+            sys.stderr.write(txt)
+    sys.stdout.flush()
+    if rc == 0 and not any(l.startswith("{") for l in txt_lines(os.path.join(tmp, "rank0.out"))):
+        print("bench.py launcher: rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def txt_lines(path):
+    with open(path) as f:
+        return f.read().splitlines()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    a = parse_args(argv)
+    have_ranks = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if a.gpus > 1 and not have_ranks:
+        raise SystemExit(launcher(a, argv))
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the line would not describe the job that ran")
 
     cpu = cpu_c1 = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.board == 9 and a.network == "tower":
-        # before any GPU context exists; C2's net for the like-for-like ratio, C1 (plumbing config) beside it
-        cpu = cpu_baseline(a.cpu_seconds, a.sims, a.filters, a.blocks, label="C2 net" if (a.sims, a.filters, a.blocks) == (400, 128, 6) else "bench net")
-        cpu_c1 = cpu_baseline(a.cpu_seconds, 64, 32, 2, label="C1")
+    if a.cpu_json:
+        if rank == 0:
+            with open(a.cpu_json) as f:
+                legs = json.load(f)
+            cpu, cpu_c1 = legs.get("cpu_baseline"), legs.get("cpu_baseline_c1")
+    elif rank == 0:
+        # before any GPU context exists in this process; with ranks started by somebody else (torchrun) the other ranks wait for
+        # rank 0 inside init_process_group, idle
+        cpu, cpu_c1 = cpu_legs(a)
 
+    import datetime
     import torch
     import torch.distributed as dist
-    dev = torch.device("cuda", local if os.environ.get("TRANSGO_DIST_BACKEND", "nccl") == "nccl" else 0)
-    torch.cuda.set_device(dev)
     backend = os.environ.get("TRANSGO_DIST_BACKEND", "nccl")        # "gloo": rehearsal of the N>1 path with several ranks on one GPU
+    dev = torch.device("cuda", local if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        pg_timeout = datetime.timedelta(seconds=float(os.environ.get("TRANSGO_PG_TIMEOUT", "1800")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=pg_timeout)
     cdev = dev if backend == "nccl" else torch.device("cpu")          # where collective payloads live
+    # what the process group really is: answered from the group, not from the arguments
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "device": int(dev.index), "name": props.name, "pid": os.getpid(),
+          "bus": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", ""))}
+    if world > 1:
+        seen = [None] * world
+        dist.all_gather_object(seen, me)
+        ranks = {"world": dist.get_world_size(), "backend": dist.get_backend(), "devices": seen,
+                 "distinct_gpus": len({(d["device"], d["bus"], d["uuid"]) for d in seen}),
+                 "launcher": os.environ.get("TRANSGO_BENCH_LAUNCHER", "external (torch.distributed.run)")}
+    else:
+        ranks = {"world": 1, "backend": None, "devices": [me], "distinct_gpus": 1, "launcher": "none"}
 
     from transgo_amd import model
     from transgo_amd.configure import Config
@@ -240,6 +366,8 @@ def main():
         one_step()
     tally["games"] = tally["positions"] = 0
     eng = sp.engine
+    # event pools sized for ONE step; they are drained into running totals after every step (the stream is idle there: the step
+    # ended with the visit-count read-back), so the roofline covers every conv launch of the timed region
     eng.ctx.call("tg_prof_enable", 1, 8192)
     eng.ctx.call("tg_prof_enable_tree", 1, 8192)
     cs0 = ctypes.c_uint64()
@@ -247,15 +375,19 @@ def main():
     st0 = eng.stats()
     fin0, drop0 = sp.games_finished, sp.games_dropped
     sp.phase_s = {}; eng.begin_move_s = 0.0
+    ms, nl, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+    nskip = ctypes.c_int64()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         one_step()
+        eng.ctx.call("tg_prof_read", ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(fl))
+        eng.ctx.call("tg_prof_read_tree", None, None, None, None)
     barrier()
     dt = time.perf_counter() - t0
     st1 = eng.stats()
-    ms, nl, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
     eng.ctx.call("tg_prof_read", ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(fl))
+    eng.ctx.call("tg_prof_skipped", ctypes.byref(nskip))
     cms, ams, nw, cs1 = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64(), ctypes.c_uint64()
     eng.ctx.call("tg_prof_read_tree", ctypes.byref(cms), ctypes.byref(ams), ctypes.byref(nw), ctypes.byref(cs1))
 
@@ -273,13 +405,13 @@ def main():
         # they only describe the configuration they were collected on
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json" if a.dtype == "f32" else "r1_pmc_traffic_f16.json")
-        if os.path.exists(tfile) and (S, a.filters, a.games, a.network) == (9, 128, 4096, "tower"):
+        if a.dtype in ("f32", "f16") and os.path.exists(tfile) and (S, a.filters, a.games, a.network) == (9, 128, 4096, "tower"):
             with open(tfile) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch_mean")
         value = sims_all / dt
         conv_tflops = (fl.value / (ms.value * 1e-3)) / 1e12 if ms.value > 0 else 0.0
         fpl = flops_per_leaf(S, 10, a.filters, a.blocks) if a.network == "tower" else None
-        peak = PEAK_F16_MATRIX_TFLOPS if a.dtype != "f32" else PEAK_F32_MATRIX_TFLOPS
+        peak = {"f32": PEAK_F32_MATRIX_TFLOPS, "f32x3": PEAK_F16_MATRIX_TFLOPS / 3.0}.get(a.dtype, PEAK_F16_MATRIX_TFLOPS)
         tree = tree_roofline(S, 10, sims, evals, depth, cs1.value - cs0.value, cms.value + ams.value, nw.value)
         if tree:
             tree["share_of_step"] = round((cms.value + ams.value) / (dt * 1e3), 4)
@@ -288,32 +420,43 @@ def main():
         info = mem.info()
         net_name = (f"{a.blocks}-block x {a.filters}-filter tower" if a.network == "tower"
                     else f"reference MainNetwork (RARRRARRRRAR+P, {a.filters} filters)")
+        gph_step = round(world * a.games * 3600.0 / (dt / a.steps * mean_len), 1) if mean_len else None
         line = {
             "metric": "MCTS simulations/sec", "value": round(value, 1), "unit": "sims/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "games_per_hour": round(games_stored / dt * 3600.0, 1),
+            "ranks": ranks,
             "config": {"workload": f"{S}x{S} Go self-play, {a.sims} sims/move, {net_name}, "
                                    f"{a.games} concurrent boards per GPU", "boards_per_gpu": a.games,
                        "parallelism": f"games sharded over {world} GPU(s), no data-path collective",
+                       "seeds": "k-th game of slot g on rank r: (k*world + r)*G + g (disjoint per job; not BASELINE.md 4's "
+                                "1000*rank + g, which collides beyond 1000 boards per rank)",
                        "step": "one move of every board (search + move selection + record + re-root) and, for the games it "
                                "finishes, device-side target generation, gather to rank 0 and append to the device replay store",
-                       "stagger": (f"slot g starts the warm-up g mod {period} plies into its game ({period - 1} untimed moves "
-                                   f"with 16-simulation searches, {stagger_s:.1f} s)") if period > 1 else "none: all boards start together"},
-            "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": peak,
+                       "stagger": (f"slot g starts the warm-up g mod {period} plies into its game (slots with g mod {period} = 0: "
+                                   f"{period - 1} plies); {period - 1} untimed moves with 16-simulation searches, {stagger_s:.1f} s") if period > 1 else "none: all boards start together"},
+            "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": round(peak, 1),
                          "unit": "TFLOP/s", "frac": round(conv_tflops / peak, 4), "traffic": traffic,
                          "traffic_note": (f"HBM bytes per full-batch launch, FETCH_SIZE x2 + WRITE_SIZE (profiles/{os.path.basename(tfile)})"
                                           if traffic is not None else "PMC traffic was collected for the 9x9 / 128-filter / 4096-board workload only"),
+                         "peak_note": ("dense fp16 MFMA peak / 3: every F->F conv is three fp16 MFMA passes (hi*hi + hi*lo + lo*hi); "
+                                       "achieved counts the conv's 2*9*F*F FLOP per row once") if a.dtype == "f32x3" else None,
                          "kernel": kernel_name(S, a.filters, a.dtype),
-                         "launches": int(nl.value), "avg_launch_ms": round(ms.value / max(1, nl.value), 4)},
+                         "launches": int(nl.value), "launches_not_timed": int(nskip.value),
+                         "avg_launch_ms": round(ms.value / max(1, nl.value), 4),
+                         "rank": 0},
             "roofline_tree": tree,
             "cpu_baseline": cpu,
             "cpu_baseline_c1": cpu_c1,
             "selfplay_games": {"finished_and_stored": games_stored, "finished_all_ranks": int(fin_all),
                                "positions_stored": tally["positions"], "mean_game_length": round(mean_len, 2) if mean_len else None,
                                "games_per_hour": round(games_stored / dt * 3600.0, 1),
-                               "games_per_hour_from_step_time": (round(world * a.games * 3600.0 / (dt / a.steps * mean_len), 1)
-                                                                 if mean_len else None),
+                               "games_per_hour_from_step_time": gph_step,
+                               "note": ("the games counted here were started before the timed region and played their first plies "
+                                        "under the stagger's 16-simulation searches (only the plies inside the timed steps are 400-"
+                                        "simulation searches); games_per_hour_from_step_time = boards x 3600 / (step time x mean "
+                                        "length) is the steady-state rate of full-strength games") if period > 1 else None,
                                "dropped_arena_overflow": int(drop_all),
                                "replay_entries": info["entries"], "consumer": "DeviceReplayMemory on rank 0 (tg_replay_append_dev)"},
             "extra": {"leaves_per_s": round(evals_all / dt, 1), "mean_depth": round(depth_all / max(1.0, sims_all), 3),
@@ -326,8 +469,9 @@ def main():
                                           "counts D2H + pi/move sampling on the host; play = record + re-root kernel + new-root evaluation; "
                                           "game_end = harvest + restart of finished slots (gather/append are outside these four)"},
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -205,11 +205,16 @@ size_t tg_net_blob_floats_arch(int board_size, int encode_dim, int filters, cons
 int tg_net_load_arch(tg_ctx* ctx, const char* arch, const float* blob, size_t n_floats, int rows_cap);
 /* Weight refresh that never stalls a search (the hand-off of trainer.py:76-79 -> self_play.py:913): there are two complete
  * weight sets; this call copies the blob to pinned memory and uploads + re-stages it into the idle set on a side stream, then
- * returns.  Searches keep running on the live set; the first network forward that finds the upload complete switches over.
+ * returns.  Searches keep running on the live set; the switch happens at a boundary only: the next tg_sp_begin_move (so one
+ * move's search, and its recorded pi, never mixes two weight sets) or the next tg_net_predict that finds the upload complete.
  * Falls back to the synchronous load when no network of this architecture is loaded yet.  One refresh in flight at a time (a
  * second call first waits for the previous one).  tg_net_load_poll: pending = 1 while a refresh is not adopted yet; wait != 0
  * blocks until it is. */
 int tg_net_load_async(tg_ctx* ctx, const char* arch, const float* blob, size_t n_floats);
+/* The same with the blob in THIS GPU's memory (e.g. the buffer an RCCL broadcast filled): copied device -> device, no host
+ * bounce.  Its contents must be complete when the call is made; the buffer is free again when the call returns.  Needs a network
+ * of this architecture already loaded. */
+int tg_net_load_async_dev(tg_ctx* ctx, const char* arch, const float* d_blob /*device*/, size_t n_floats);
 int tg_net_load_poll(tg_ctx* ctx, int wait, int* pending);
 /* main_prediction (model.py:17-20) on host buffers: obs f32[n][C][S][S] -> policy f32[n][A] (softmax), value f32[n]
  * (tanh), own f32[n][S*S] (tanh; may be NULL). */
@@ -217,6 +222,9 @@ int tg_net_predict(tg_ctx* ctx, const float* obs, int n_rows, float* policy, flo
 /* HIP-event timing of the dominant kernel (3x3 conv F->F) on the launch stream: enable, run, read totals. */
 int tg_prof_enable(tg_ctx* ctx, int on, int max_launches);
 int tg_prof_read(tg_ctx* ctx, double* conv_ms, int64_t* conv_launches, double* conv_flops);
+/* tg_prof_read drains the event pool into running totals (call it between steps); launches that found the pool full are not in
+ * the totals and are counted here (0 = the totals cover every launch since tg_prof_enable). */
+int tg_prof_skipped(tg_ctx* ctx, int64_t* launches);
 /* The same for the tree stage (k_collect = selection + leaf step + pseudo-expansion + feature planes, self_play.py:607-650;
  * k_absorb = complete_update + backup, :651-654, :727-764): event time per kind, number of waves, and the number of children
  * scored by PUCT summed over all selection levels since the last reset (mean fan-out = children_scored / depth_sum). */

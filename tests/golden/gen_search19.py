@@ -79,7 +79,8 @@ def main():
     max_step = 40                                              # short games: the ply limit ends them (go_env.cc:67)
     tmp, cfg, env, self_play = load_reference_19(max_step)
     try:
-        cases = [("sharp", 21, 48, 60), ("flat", 22, 24, 60), ("sharp", 23, 160, 6), ("sharp", 24, 800, 2)]   # the last = BASELINE configs[3] search depth
+        cases = [("sharp", 21, 48, 60), ("flat", 22, 24, 60), ("sharp", 23, 160, 6), ("sharp", 24, 800, 2),   # BASELINE configs[3] search depth
+                 ("sharp", 25, 1600, 2)]  # BASELINE configs[4] search depth (1600 simulations/move)
         blob = {}
         for name, seed, sims, mm in cases:
             r = play(cfg, env, self_play, evaluators.BY_NAME[name], seed, sims, mm)

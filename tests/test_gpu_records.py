@@ -114,24 +114,30 @@ def _actor_worker(rank, world, port, q, backend):
     from transgo_amd.replay_buffer import DeviceReplayMemory, ReplayMemory_Random
     from transgo_amd.self_play import SelfPlay
     from transgo_amd.shared_storage import SharedStorage
+    from transgo_amd import distributed
     gpu = rank if backend == "nccl" else 0
-    if backend == "nccl":
-        torch.cuda.set_device(gpu)
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", gpu))
-    else:
-        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    distributed.init_process_group(backend, rank, world, device_index=gpu, timeout_s=300.0, init_method=f"tcp://127.0.0.1:{port}")
     cfg = Config(num_simulation=24, max_step=5, buffer_size=8 * 1024)
     G = 3 + rank                                                     # ragged shards
     actor = SelfPlay(cfg, n_games=G, device=gpu, rank=rank, world=world, evaluator=evaluators.sharp)
     st = mem = None
     if rank == 0:
-        st = SharedStorage({"weights": None, "now_play_steps": 0, "now_play_games": 0, "now_train_steps": 10 ** 9,
+        # the trainer is BEHIND when the first games finish (now_train_steps 0) and catches up 3 s into the run: every rank must
+        # sit out the same 0.5-s rounds on the host -- nobody inside a pending collective -- and then resume
+        st = SharedStorage({"weights": None, "now_play_steps": 0, "now_play_games": 0, "now_train_steps": 0,
                             "train_play_ratio": 0.075, "adjust_train_play_ratio": True, "game_total_num": 1e8,
                             "adjust_lr": False, "learn_rate": 1e-4}, cfg)
         mem = DeviceReplayMemory(cfg, capacity_positions=1024, device=gpu) if backend == "nccl" else ReplayMemory_Random(cfg)
+        import threading
+        import time as _t
+
+        def trainer():
+            _t.sleep(3.0)
+            st.set_info("now_train_steps", 10 ** 9)
+        threading.Thread(target=trainer, daemon=True).start()
     actor.continuous_self_play(st, mem, max_moves=11)                # 2 full generations (5 moves each) + 1 move
-    out = {"rank": rank, "finished_local": actor.worker.games_finished, "G": G, "dropped": actor.worker.games_dropped}
+    out = {"rank": rank, "finished_local": actor.worker.games_finished, "G": G, "dropped": actor.worker.games_dropped,
+           "rounds": actor.throttle_rounds}
     if rank == 0:
         info = mem.info()
         out.update(steps=st.get_info("now_play_steps"), games=st.get_info("now_play_games"),
@@ -177,12 +183,13 @@ def _run_actor_ranks(backend):
     assert all(p.exitcode == 0 for p in ps)
     r0, r1 = res
     assert r0["dropped"] == r1["dropped"] == 0
+    assert r0["rounds"] == r1["rounds"] >= 1                          # the stalled trainer was waited for by both ranks together
     assert r0["weights_ok"] and r1["weights_ok"]                      # the second weight version reached both ranks' GPUs
     assert r0["finished_local"] == 2 * 3 and r1["finished_local"] == 2 * 4
     assert r0["games"] == 14                                          # every rank's finished games reached the owner
     assert r0["entries"] == 14 * 5 * 8                                # 5 positions per game, 8 reference entries per position
-    # now_play_steps: the owner adds G_owner * world per step (shards are equal-sized in production; ragged only here)
-    assert r0["steps"] == 11 * 3 * 2
+    # now_play_steps: one per move actually played, summed over the ranks inside the gather's size exchange (3 + 4 live slots)
+    assert r0["steps"] == 11 * 7
     return res
 
 

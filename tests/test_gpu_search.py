@@ -257,3 +257,37 @@ def test_wp_mcts_mirror_follows_the_oracle_call_by_call():
     oa, opi, oobs, _ = o.search_move(selfplay=False)
     assert a == oa and np.array_equal(pi, opi) and np.array_equal(obs, oobs)
     m.close()
+
+
+def test_wp_mcts_mirror_reset_root_keeps_the_random_stream():
+    """the reference's reset_root (self_play.py:595-605) only rebuilds the root; NumPy's global stream keeps advancing
+    across games (continuous_self_play calls it at the top of every game, self_play.py:915).  Two games through reset_root must
+    follow the oracle's ONE RandomState -- and therefore differ from each other."""
+    from oracle.go_oracle import OracleGoEnv
+    from oracle.wp_mcts import OracleSearch
+    from transgo_amd.configure import Config
+    from transgo_amd.self_play import WP_MCTS
+    cfg = Config(num_simulation=32, max_step=6)
+    seed = 77
+    m = WP_MCTS(cfg, evaluator=evaluators.sharp, seed=seed)
+    o = OracleSearch(OracleGoEnv(max_step=6), evaluators.sharp, np.random.RandomState(seed), num_simulation=32)
+    games = []
+    for game in range(3):
+        if game:
+            m.reset_root(); o.reset_root()
+        moves = []
+        for ply in range(6):
+            a, pi, obs = m.get_action_probs(is_selfplay=True)
+            oa, opi, oobs, _ = o.search_move(selfplay=True)
+            assert a == oa and np.array_equal(pi, opi) and np.array_equal(obs, oobs), (game, ply)
+            moves.append((a, pi.tobytes()))
+            done = m.update_with_action(a)
+            assert done == o.advance(oa)
+            if done:
+                break
+        games.append(moves)
+    key, pos = m.engine.rng_state(0)
+    ok, opos = o.rng.get_state()[1], o.rng.get_state()[2]
+    assert np.array_equal(key, ok) and pos == opos
+    assert games[0] != games[1] and games[1] != games[2]          # re-seeding every game would make them identical
+    m.close()

@@ -214,3 +214,61 @@ def test_staggered_start_spreads_game_ends_without_changing_games():
         assert q.winner == r.winner and q.players == r.players
         assert all(np.array_equal(a, b) for a, b in zip(q.visits, r.visits))
         assert all(np.array_equal(a, b) for a, b in zip(q.observations, r.observations))
+
+
+def test_default_actor_takes_a_mainnetwork_state_dict():
+    """What the reference trainer publishes is a MainNetwork state_dict (model.py:49-76: 9 residual + 3 attention blocks, attention
+    policy head).  A DEFAULT-configured actor (tower layout) handed that dict through the storage must switch layouts by the key
+    names and search with it: one searched move of every game, visit counts equal to the oracle search driving the torch
+    restatement of MainNetwork with the same weights and seeds (networks agree to ~1e-7, so allow one near-tie to split)."""
+    import torch
+    from oracle.go_oracle import OracleGoEnv
+    from oracle.net import TransGoMain
+    from oracle.wp_mcts import OracleSearch
+    from transgo_amd import model
+    from transgo_amd.configure import Config
+    from transgo_amd.replay_buffer import ReplayMemory_Random
+    from transgo_amd.self_play import SelfPlay
+    from transgo_amd.shared_storage import SharedStorage
+    torch.manual_seed(5); torch.set_num_threads(4)
+    net = TransGoMain(9, 10, 128).eval()
+    gen = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) + 0.5)
+            if hasattr(m, "gamma"):
+                m.gamma.copy_(0.5 + torch.rand(1, generator=gen))
+    sd = {k: t.numpy() for k, t in net.state_dict().items()}
+    cfg = Config(num_simulation=24, max_step=30, buffer_size=1024)            # everything else: the reference defaults (tower, 128)
+    assert getattr(cfg, "network", "tower") == "tower"
+    G = 4
+    actor = SelfPlay(cfg, n_games=G)
+    assert not actor.worker.arch.policy_attention
+    st = SharedStorage({"weights": sd, "now_play_steps": 0, "now_play_games": 0, "now_train_steps": 1,
+                        "train_play_ratio": 0.075, "adjust_train_play_ratio": False, "game_total_num": 1e8,
+                        "adjust_lr": False, "learn_rate": 1e-4}, cfg)
+    actor._refresh_weights(st)                                                 # self_play.py:913
+    assert actor.worker.arch.code == model.transgo_arch().code
+    eng = actor.worker.engine
+    actor.worker.start()
+    eng.search()
+    vis, rn, pl, stp, ob = eng.root_info()
+
+    def ev(obs):
+        with torch.no_grad():
+            p, v, _ = net.main_prediction(torch.from_numpy(obs))
+        return p.numpy(), v.numpy()
+    same = 0
+    for g in range(G):
+        o = OracleSearch(OracleGoEnv(max_step=30), ev, np.random.RandomState(int(actor.worker.seeds[g])), num_simulation=24)
+        a, pi, obs, _ = o.search_move()
+        raw = np.array([o.root.kids[i].n if i in o.root.kids else 0 for i in range(82)])
+        assert raw.sum() == vis[g].sum() and np.array_equal(obs, ob[g])
+        same += int(np.array_equal(raw, vis[g]))
+    print(f"MainNetwork through a default actor: {same}/{G} first-move visit vectors identical to the oracle's")
+    assert same >= G - 1
+    # and the actor loop runs on with it
+    actor.continuous_self_play(st, ReplayMemory_Random(cfg), max_moves=2)
+    assert st.get_info("now_play_steps") == 2 * G and eng.stats()["errors"] == 0

@@ -386,3 +386,101 @@ def test_wp_mcts_mirror_has_the_reference_call_surface():
     assert sig(WP_MCTS.get_action_probs) == [("is_selfplay", True), ("now_train_step", 0)]
     assert sig(WP_MCTS.select_action) == [("gamestate", inspect._empty)]
     assert sig(WP_MCTS.update_with_action) == [("fall_action", inspect._empty)]
+
+
+# ---- the multi-rank ACTOR loop's control flow on CPU (gloo): fake engine, real SelfPlay.continuous_self_play -------------------
+class _FakeWorker:
+    """What SelfPlay.continuous_self_play uses of BatchedSelfPlay, without a GPU: every `period`-th move finishes one fake game."""
+
+    def __init__(self, rank, G, period=2, die_at=None):
+        self.rank, self.G, self.S, self.device, self.filters, self.blocks = rank, G, 9, 0, 32, 2
+        self.config = Config(num_features=32, num_blocks=2)
+        self.arch = model.tower_arch(2)
+        self.moves, self.last_live, self.period, self.die_at = 0, 0, period, die_at
+        self.blobs, self.games_finished = [], 0
+
+    def advance(self, device=False):
+        from transgo_amd import records
+        self.moves += 1
+        if self.die_at is not None and self.moves == self.die_at:
+            os._exit(3)                                   # a rank that dies mid-run (no destroy_process_group, no goodbye)
+        self.last_live = self.G - (1 if self.moves == 1 else 0)      # one parked slot on the first move
+        if self.moves % self.period:
+            return None
+        self.games_finished += 1
+        return records.from_records(_fake_games(np.random.RandomState(self.moves + 10 * self.rank), [2], seed0=self.moves), 9, 10)
+
+    def set_weights_blob(self, blob, background=False):
+        self.blobs.append(np.asarray(blob, np.float32).copy())
+
+
+def _loop_worker(rank, world, port, q, scenario):
+    import threading
+    import time
+    from transgo_amd import distributed
+    from transgo_amd.self_play import SelfPlay
+    distributed.init_process_group("gloo", rank, world, timeout_s=20.0, init_method=f"tcp://127.0.0.1:{port}")
+    actor = SelfPlay.__new__(SelfPlay)
+    actor.config = Config(num_features=32, num_blocks=2)
+    actor.worker = _FakeWorker(rank, 3 + rank, die_at=2 if (scenario == "death" and rank == 1) else None)
+    actor._train_steps_seen = actor._blob_digest = None
+    st = mem = None
+    if rank == 0:
+        st = SharedStorage({"weights": model.random_weights(9, 10, 32, 2, seed=1), "now_play_steps": 0, "now_play_games": 0,
+                            "now_train_steps": 0, "train_play_ratio": 0.5, "adjust_train_play_ratio": True,
+                            "game_total_num": 1e8, "adjust_lr": False, "learn_rate": 1e-4}, actor.config)
+        mem = ReplayMemory_Random(Config(buffer_size=4096))
+        if scenario == "stall":
+            def trainer():                                 # the trainer catches up (and publishes new weights) after 3 s
+                time.sleep(3.0)
+                st.set_info({"weights": model.random_weights(9, 10, 32, 2, seed=2), "now_train_steps": 10 ** 9})
+            threading.Thread(target=trainer, daemon=True).start()
+    t0 = time.time()
+    actor.continuous_self_play(st, mem, max_moves=5)
+    out = {"rank": rank, "seconds": time.time() - t0, "rounds": actor.throttle_rounds, "moves": actor.worker.moves,
+           "blobs": [float(b.sum()) for b in actor.worker.blobs]}
+    if rank == 0:
+        out.update(steps=st.get_info("now_play_steps"), games=st.get_info("now_play_games"), entries=mem.info()["index"])
+    q.put(out)
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def _run_loop(scenario):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_loop_worker, args=(r, 2, port, q, scenario)) for r in range(2)]
+    [p.start() for p in ps]
+    return ps, q
+
+
+def test_actor_loop_stalled_trainer_two_ranks_gloo():
+    """rank 0 used to sleep in the train/play throttle while rank 1 sat inside the next broadcast.  Now the
+    wait is a collective decision (control word per round): with the trainer stalled for 3 s BOTH ranks idle on the host in
+    0.5-s rounds, the same number of them, and both resume when now_train_steps moves -- with the weights the trainer published
+    meanwhile delivered to every rank."""
+    ps, q = _run_loop("stall")
+    res = sorted((q.get(timeout=120) for _ in range(2)), key=lambda d: d["rank"])
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    r0, r1 = res
+    assert r0["moves"] == r1["moves"] == 5
+    assert r0["rounds"] == r1["rounds"] >= 4 and min(r0["seconds"], r1["seconds"]) >= 2.5
+    want = [float(model.pack_weights(model.random_weights(9, 10, 32, 2, seed=s), 9, 10, 32, 2).sum()) for s in (1, 2)]
+    assert r0["blobs"] == r1["blobs"] == want             # first version at move 1, second after the stall, on both ranks
+    assert r0["games"] == 4 and r0["entries"] == 4 * 2 * 8                      # moves 2 and 4 finish one 2-ply game per rank
+    assert r0["steps"] == 5 * 7 - 2                       # moves actually played: 3 + 4 slots, one parked each on the first move
+
+
+def test_actor_loop_peer_death_is_a_nonzero_exit_not_a_hang():
+    """A rank that dies leaves the others inside a collective: with the explicit process-group timeout (20 s here) the survivor
+    ends with an error instead of waiting forever."""
+    import time
+    ps, q = _run_loop("death")
+    t0 = time.time()
+    [p.join(90) for p in ps]
+    assert all(not p.is_alive() for p in ps), "a rank is still hanging"
+    assert ps[1].exitcode == 3 and ps[0].exitcode not in (0, None)
+    assert time.time() - t0 < 80

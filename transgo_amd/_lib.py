@@ -71,10 +71,12 @@ SIGNATURES = {
     "tg_net_blob_floats_arch": (ctypes.c_size_t, [ctypes.c_int] * 3 + [ctypes.c_char_p]),
     "tg_net_load_arch": (ctypes.c_int, [_vp, ctypes.c_char_p, _vp, ctypes.c_size_t, ctypes.c_int]),
     "tg_net_load_async": (ctypes.c_int, [_vp, ctypes.c_char_p, _vp, ctypes.c_size_t]),
+    "tg_net_load_async_dev": (ctypes.c_int, [_vp, ctypes.c_char_p, _vp, ctypes.c_size_t]),
     "tg_net_load_poll": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "tg_net_predict": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
     "tg_prof_enable": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "tg_prof_read": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]),
+    "tg_prof_skipped": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
     "tg_prof_enable_tree": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "tg_prof_read_tree": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
                                           ctypes.POINTER(ctypes.c_uint64)]),

@@ -75,4 +75,5 @@ struct Engine {
 
 extern "C" int tg_net_forward(tg_ctx* ctx, int rows);   // pending batch (obs_bits through row_slot) -> policy[rows], value[rows] on ctx->stream
 extern "C" void tg_net_destroy(tg_ctx* ctx);
+extern "C" int tg_net_adopt_ready(tg_ctx* ctx);         // tg_sp_begin_move: a completed background weight refresh becomes the live set
 extern "C" int tg_net_load_arch(tg_ctx* ctx, const char* arch, const float* blob, size_t n_floats, int rows_cap);

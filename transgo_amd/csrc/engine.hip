@@ -882,6 +882,9 @@ int tg_sp_begin_move(tg_ctx* ctx, int selfplay, int num_simulation) {
     const int G = e->G, A = ctx->A;
     if (e->batch_kind != BATCH_NONE) TG_FAIL(ctx, TG_ERR_STATE, "tg_sp_begin_move: an evaluation batch is pending");
     if (num_simulation <= 0) num_simulation = ctx->cfg.num_simulation;
+    // weights change between moves only (the reference swaps them at game start, self_play.py:913; with G games in lock step the
+    // move boundary is the closest point every game shares): one search = one weight set
+    { int rc = tg_net_adopt_ready(ctx); if (rc) return rc; }
     if (selfplay) {                                                    // root.dirichlet_prior(), self_play.py:659-660
         int32_t* d_nchild = e->d_i32;
         TG_LAUNCH(ctx, k_root_info, G, e->dev, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,

@@ -63,6 +63,7 @@ struct Net {
     hipStream_t side = nullptr; hipEvent_t loaded = nullptr, swapped = nullptr; float* pinned = nullptr;
     // profiling of the dominant kernel (3x3 conv F->F) with HIP events on the launch stream
     bool prof = false; std::vector<hipEvent_t> ev; size_t ev_used = 0; double conv_ms = 0; long conv_launches = 0; double conv_flops = 0;
+    long conv_skipped = 0;                         // launches that found the event pool full (drain it with tg_prof_read between steps)
 };
 
 }  // namespace tg
@@ -1200,6 +1201,7 @@ struct ProfScope {
     Net* n; hipStream_t st; bool on;
     ProfScope(Net* net, hipStream_t s, double flops) : n(net), st(s), on(net->prof && net->ev_used + 2 <= net->ev.size()) {
         if (on) { (void)hipEventRecord(n->ev[n->ev_used], st); n->conv_flops += flops; n->conv_launches++; }
+        else if (net->prof) n->conv_skipped++;
     }
     ~ProfScope() { if (on) { (void)hipEventRecord(n->ev[n->ev_used + 1], st); n->ev_used += 2; } }
 };
@@ -1410,10 +1412,12 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
 
 int adopt_pending(tg_ctx* ctx, Net* n, bool wait);
 
+// A finished background refresh takes over only where the CALLER is at a boundary: tg_net_predict (every call stands alone) and
+// tg_sp_begin_move (tg_net_adopt_ready) -- never in the middle of a move's search, so one search tree and one recorded pi never
+// mix evaluations of two weight sets and the switch point does not depend on upload timing within a move.
 int forward(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, float* value, float* own) {
     if (rows <= 0) return TG_OK;
     if (rows > n->rows_cap) TG_FAIL(ctx, TG_ERR_ARG, "network batch larger than the allocated activation buffers");
-    { int rc = adopt_pending(ctx, n, /*wait=*/false); if (rc) return rc; }      // a finished background refresh takes over here
 #define TG_NET_CASE(SZ, FF) if (n->S == SZ && n->F == FF) return forward_t<SZ, FF>(ctx, n, obs, rows, policy, value, own)
     TG_NET_CASE(9, 32); TG_NET_CASE(9, 64); TG_NET_CASE(9, 128); TG_NET_CASE(9, 256);
     TG_NET_CASE(19, 128); TG_NET_CASE(19, 256);
@@ -1487,9 +1491,15 @@ void bind_weights(Net* n, int k) {
 }
 
 // Upload `blob` into weight set k and rebuild its stage-ordered copies, everything on `st` (no synchronisation here).
-int fill_weight_set(tg_ctx* ctx, Net* n, int k, const float* blob, hipStream_t st) {
+int fill_weight_set(tg_ctx* ctx, Net* n, int k, const float* blob, hipStream_t st, bool blob_on_device = false) {
     const int F = n->F;
-    TG_HIP(ctx, hipMemcpyAsync(n->sets[k].blob, blob, sizeof(float) * n->blob_floats, hipMemcpyHostToDevice, st));
+    TG_HIP(ctx, hipMemcpyAsync(n->sets[k].blob, blob, sizeof(float) * n->blob_floats,
+                               blob_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    if (blob_on_device) {
+        // the library keeps no caller pointer after a call returns: the copy out of the caller's buffer is over before the
+        // (asynchronous) restaging starts
+        TG_HIP(ctx, hipStreamSynchronize(st));
+    }
     Net view = *n;                                        // pointer fields of set k without disturbing the live binding
     bind_weights(&view, k);
     if (n->prec >= 1) {
@@ -1646,6 +1656,23 @@ int tg_net_load_async(tg_ctx* ctx, const char* arch_c, const float* blob, size_t
     return TG_OK;
 }
 
+// The same with the blob already in THIS GPU's memory (what an RCCL broadcast delivered): device -> device into the retired set,
+// no host bounce.  The contents of d_blob must be complete when the call is made (synchronise the producing stream first); the
+// buffer may be reused as soon as the call returns.
+int tg_net_load_async_dev(tg_ctx* ctx, const char* arch_c, const float* d_blob, size_t n_floats) {
+    if (!ctx || !d_blob || !arch_c) return TG_ERR_ARG;
+    Net* n = ctx->eng ? ctx->eng->net : nullptr;
+    if (!n || n->arch != arch_c || n->blob_floats != n_floats || n->prec != ctx->cfg.net_precision)
+        TG_FAIL(ctx, TG_ERR_STATE, "tg_net_load_async_dev: needs a network of this architecture already loaded (tg_net_load_arch first)");
+    TG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    { int rc = adopt_pending(ctx, n, /*wait=*/true); if (rc) return rc; }
+    TG_HIP(ctx, hipStreamWaitEvent(n->side, n->swapped, 0));
+    { int rc = fill_weight_set(ctx, n, n->active ^ 1, d_blob, n->side, /*blob_on_device=*/true); if (rc) return rc; }
+    TG_HIP(ctx, hipEventRecord(n->loaded, n->side));
+    n->pending = true;
+    return TG_OK;
+}
+
 // pending = 1 while an asynchronous refresh has not been adopted yet; wait != 0 blocks until it is (and adopts it).
 int tg_net_load_poll(tg_ctx* ctx, int wait, int* pending) {
     if (!ctx || !ctx->eng || !ctx->eng->net) return TG_ERR_STATE;
@@ -1672,6 +1699,12 @@ void tg_net_destroy(tg_ctx* ctx) {
     ctx->eng->net = nullptr;
 }
 
+// Move boundary of the engine (tg_sp_begin_move): a completed background refresh becomes the live set here, and only here.
+int tg_net_adopt_ready(tg_ctx* ctx) {
+    if (!ctx || !ctx->eng || !ctx->eng->net) return TG_OK;
+    return adopt_pending(ctx, ctx->eng->net, /*wait=*/false);
+}
+
 int tg_net_forward(tg_ctx* ctx, int rows) {
     Engine* e = ctx->eng;
     if (!e || !e->net) TG_FAIL(ctx, TG_ERR_STATE, "no network weights loaded (tg_net_load)");
@@ -1687,6 +1720,7 @@ int tg_net_predict(tg_ctx* ctx, const float* obs, int n_rows, float* policy, flo
     if (!ctx || !ctx->eng || !ctx->eng->net) { if (ctx) ctx->err = "no network weights loaded (tg_net_load)"; return TG_ERR_STATE; }
     TG_HIP(ctx, hipSetDevice(ctx->cfg.device));
     Net* n = ctx->eng->net;
+    { int rc = adopt_pending(ctx, n, /*wait=*/false); if (rc) return rc; }      // a finished background refresh takes over between calls
     const size_t P = n->P, A = n->A, C = n->C;
     int done = 0;
     tg::DevBuf& din = ctx->env_f32; tg::DevBuf& dout = ctx->env_in;
@@ -1716,7 +1750,7 @@ int tg_prof_enable(tg_ctx* ctx, int on, int max_launches) {
     if (on) {
         const size_t want = 2 * (size_t)(max_launches > 0 ? max_launches : 4096);
         while (n->ev.size() < want) { hipEvent_t ev; TG_HIP(ctx, hipEventCreate(&ev)); n->ev.push_back(ev); }
-        n->ev_used = 0; n->conv_ms = 0; n->conv_launches = 0; n->conv_flops = 0;
+        n->ev_used = 0; n->conv_ms = 0; n->conv_launches = 0; n->conv_flops = 0; n->conv_skipped = 0;
     }
     n->prof = on != 0;
     return TG_OK;
@@ -1734,6 +1768,14 @@ int tg_prof_read(tg_ctx* ctx, double* conv_ms, int64_t* conv_launches, double* c
     if (conv_ms) *conv_ms = n->conv_ms;
     if (conv_launches) *conv_launches = n->conv_launches;
     if (conv_flops) *conv_flops = n->conv_flops;
+    return TG_OK;
+}
+
+// Launches of the dominant kernel that were NOT timed since tg_prof_enable(ctx, 1, n) because the event pool was full
+// (tg_prof_read drains the pool into the running totals; 0 here = the totals cover every launch).
+int tg_prof_skipped(tg_ctx* ctx, int64_t* launches) {
+    if (!ctx || !ctx->eng || !ctx->eng->net) return TG_ERR_STATE;
+    if (launches) *launches = ctx->eng->net->conv_skipped;
     return TG_OK;
 }
 

@@ -19,19 +19,57 @@ def _active():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
-def gather_harvest(h, S, C, dst=0, device_index=0):
+def init_process_group(backend, rank, world, device_index=None, timeout_s=1800.0, init_method=None):
+    """torch.distributed.init_process_group with the two things the actor loop relies on spelt out: an EXPLICIT timeout (every
+    collective of the loop is short -- a control word, a size exchange, a payload -- so a rank that waits longer than this has
+    lost a peer; gloo then raises in the waiting rank, RCCL's watchdog aborts it: either way the process ends non-zero instead
+    of hanging), and, for RCCL, the device bound at creation (eager communicator, no lazy init inside the first collective)."""
+    import datetime
+    kw = dict(rank=rank, world_size=world, timeout=datetime.timedelta(seconds=float(timeout_s)))
+    if init_method:
+        kw["init_method"] = init_method
+    if backend == "nccl":
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # this pool's hosts share GPU memory through dmabuf handles only
+        dev = torch.device("cuda", 0 if device_index is None else device_index)
+        torch.cuda.set_device(dev)
+        kw["device_id"] = dev
+    dist.init_process_group(backend, **kw)
+
+
+def control_exchange(values, src=0, device_index=0):
+    """One small int64 broadcast from `src`: the per-move control word of the actor loop (wait / weights-follow flags).  Every
+    rank passes a list of the same length (only src's content counts) and gets src's values back."""
+    if not _active():
+        return [int(v) for v in values]
+    dev = torch.device("cuda", device_index) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=src)
+    return [int(v) for v in t.tolist()]
+
+
+def gather_harvest(h, S, C, dst=0, device_index=0, live=None):
     """Every rank contributes the games it finished this step (a records.Harvest or None); rank `dst` returns the list of
     all non-empty batches in rank order (its own included), every other rank returns [].  One tiny all_gather of
-    (games, positions) per call; payloads move only when somebody finished a game."""
+    (games, positions, live) per call; payloads move only when somebody finished a game.  `live` (optional) = how many of this
+    rank's slots really played a move this step; with it the call returns (batches, sum of live over all ranks) -- what
+    now_play_steps advances by (self_play.py:928 counts moves that were played, not slots)."""
     if not _active():
-        return [h] if h is not None else []
+        out = [h] if h is not None else []
+        return out if live is None else (out, int(live))
     world, rank = dist.get_world_size(), dist.get_rank()
     nccl = dist.get_backend() == "nccl"
     dev = torch.device("cuda", device_index) if nccl else torch.device("cpu")
-    mine = torch.tensor([h.n_games, h.n_positions] if h is not None else [0, 0], dtype=torch.int64, device=dev)
-    sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    mine = torch.tensor(([h.n_games, h.n_positions] if h is not None else [0, 0]) + [int(live or 0)], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(3, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes, mine)
-    sizes = [tuple(int(x) for x in s.tolist()) for s in sizes]
+    sizes3 = [tuple(int(x) for x in s.tolist()) for s in sizes]
+    live_total = sum(x[2] for x in sizes3)
+    sizes = [x[:2] for x in sizes3]
+    batches = _gather_payloads(h, S, C, dst, sizes, world, rank, nccl, dev)
+    return batches if live is None else (batches, live_total)
+
+
+def _gather_payloads(h, S, C, dst, sizes, world, rank, nccl, dev):
     if not any(g for g, _ in sizes):
         return []
 
@@ -88,12 +126,21 @@ def gather_harvest(h, S, C, dst=0, device_index=0):
     return out
 
 
-def broadcast_weights(blob, src=0, device=None):
+def broadcast_weights(blob, src=0, device=None, n_floats=None):
     """Weight refresh for every rank (the Ray `get_info("weights")` of self_play.py:913): one broadcast of the packed,
-    BN-folded float32 blob."""
+    BN-folded float32 blob.  Rank `src` passes the blob (NumPy); the others may pass None with `n_floats`.  Returns the blob
+    WHERE THE BACKEND DELIVERED IT: over RCCL a float32 tensor in this rank's GPU memory, complete on return (the stream is
+    synchronised), which goes to the network device -> device (tg_net_load_async_dev: no host bounce on the receiving ranks);
+    over gloo a NumPy array."""
     if not _active():
         return blob
     dev = device if device is not None else torch.device("cpu")
-    t = torch.from_numpy(np.ascontiguousarray(blob, np.float32)).to(dev)
+    if blob is not None:
+        t = torch.from_numpy(np.ascontiguousarray(blob, np.float32)).to(dev)
+    else:
+        t = torch.empty(int(n_floats), dtype=torch.float32, device=dev)
     dist.broadcast(t, src=src)
-    return t.cpu().numpy()
+    if t.is_cuda:
+        torch.cuda.synchronize(dev)         # the consumer is libtransgo_hip on its own streams: the payload must really be there
+        return t
+    return t.numpy()

@@ -97,6 +97,7 @@ class BatchedSelfPlay:
         self.games_started = np.zeros(n_games, np.int64)
         self.seeds = np.zeros(n_games, np.uint32)          # seed of the game now running in each slot
         self.moves_played = 0
+        self.last_live = 0
         self.games_finished = 0
         self.games_dropped = 0                             # games abandoned because their tree outgrew the arena
         self.phase_s = {}
@@ -120,8 +121,14 @@ class BatchedSelfPlay:
 
     def set_weights_blob(self, blob, background=False):
         """Packed blob -> GPU.  background=True: upload into the idle weight set on a side stream (tg_net_load_async) while
-        searches continue on the live one; the switch happens at the first network forward after the upload completed."""
+        searches continue on the live one; the switch happens at the next move boundary (tg_sp_begin_move) after the upload
+        completed, so one move's search never mixes two weight sets.  A float32 torch tensor in this GPU's memory (what an RCCL
+        broadcast delivered) is taken device -> device (tg_net_load_async_dev)."""
         import ctypes
+        if hasattr(blob, "is_cuda") and blob.is_cuda:
+            assert blob.dtype.is_floating_point and blob.element_size() == 4 and blob.is_contiguous()
+            self.engine.ctx.call("tg_net_load_async_dev", self.arch.code.encode(), ctypes.c_void_p(blob.data_ptr()), blob.numel())
+            return
         blob = np.ascontiguousarray(blob, np.float32)
         if background:
             self.engine.ctx.call("tg_net_load_async", self.arch.code.encode(), blob.ctypes.data_as(ctypes.c_void_p), blob.size)
@@ -179,6 +186,7 @@ class BatchedSelfPlay:
         done = eng.play(actions)
         t3 = time.perf_counter()
         self.moves_played += live
+        self.last_live = live                                           # slots that really played this move (not parked / over / in error)
         h = None
         if self._parked is not None:
             done = done & ~self._parked                                 # a parked slot reports "over" without having played
@@ -243,10 +251,15 @@ class WP_MCTS:
                 raise ValueError("WP_MCTS needs a model (state_dict or object with get_weights()) or an evaluator")
             self._sp.set_weights(model.get_weights() if hasattr(model, "get_weights") else model)
         self.root = _Root(self)
-        self.reset_root()                              # self_play.py:592-593
+        self.engine.reset(np.array([self.seed], np.uint32))       # np.random.seed(seed), ONCE + reset_root (self_play.py:592-593)
 
-    def reset_root(self):                              # self_play.py:595-605: empty board, root expanded with raw priors
-        self.engine.reset(np.array([self.seed], np.uint32))
+    def reset_root(self):
+        """self_play.py:595-605: empty board, root expanded with raw priors.  The random stream is NOT touched -- the reference
+        draws from NumPy's global stream, which keeps advancing from one game to the next (continuous_self_play calls reset_root
+        at the top of every game): a second game draws different Dirichlet noise and moves than the first."""
+        streams = self.engine.rng_streams()
+        self.engine.reset(np.array([self.seed], np.uint32))       # tg_sp_reset re-seeds the slot's stream ...
+        self.engine.set_rng_streams(streams)                      # ... which continues where the last game left it
 
     def get_action_probs(self, is_selfplay=True, now_train_step=0):
         """self_play.py:657-687 -> (action, pi, encode(root)): root noise if is_selfplay, num_simulation more visits at the root,
@@ -326,29 +339,56 @@ class SelfPlay:
         self._blob_digest = digest
         return blob
 
-    def _refresh_weights(self, shared_storage_worker):
-        """self_play.py:913.  With several ranks, rank 0 asks the storage actor and every other rank receives the packed
-        blob by one RCCL broadcast (transgo_amd.distributed.broadcast_weights), only when the content changed."""
+    def _throttled(self, st):
+        """The reference's train/play throttle (self_play.py:970-980), asked of the storage once."""
+        return bool(_get(_call(st.get_info, "now_train_steps")) / max(1, _get(_call(st.get_info, "now_play_steps")))
+                    < _get(_call(st.get_info, "train_play_ratio"))
+                    and _get(_call(st.get_info, "adjust_train_play_ratio"))
+                    and _get(_call(st.get_info, "now_play_games")) < _get(_call(st.get_info, "game_total_num")))
+
+    def _move_prologue(self, shared_storage_worker, throttle):
+        """Top of a move for EVERY rank: the throttle wait of self_play.py:970-980 and the weight refresh of :913, decided by
+        rank 0 (the rank that talks to the storage) and shared through ONE small broadcast per round (distributed.
+        control_exchange): word 0 = "the trainer is behind, everybody sleeps 0.5 s and asks again", word 1 = "a new packed
+        blob follows" (2: of the MainNetwork layout).  While rank 0 waits for the trainer every rank sleeps on the host between
+        two short collectives -- nobody sits inside a pending broadcast for as long as the trainer is slow (over RCCL that is
+        a watchdog abort once the process-group timeout passes)."""
+        from .distributed import broadcast_weights, control_exchange
         dist, multi, rank, _ = self._dist()
         wk = self.worker
-        blob = self._fetch_blob(shared_storage_worker) if rank == 0 else None
+        waited = 0
+        while True:
+            wait = bool(rank == 0 and throttle and self._throttled(shared_storage_worker))
+            blob = None
+            if rank == 0 and not wait:
+                blob = self._fetch_blob(shared_storage_worker)
+            flag = 0 if blob is None else (2 if wk.arch.policy_attention else 1)
+            if multi:
+                wait, flag = control_exchange([int(wait), flag], src=0, device_index=wk.device)
+            if not wait:
+                break
+            waited += 1
+            time.sleep(0.5)
+        self.throttle_rounds = getattr(self, "throttle_rounds", 0) + waited
+        if not flag:
+            return
         if not multi:
-            if blob is not None:
-                wk.set_weights_blob(blob, background=True)
+            wk.set_weights_blob(blob, background=True)
             return
         import torch
-        from .distributed import broadcast_weights
         dev = torch.device("cuda", wk.device) if dist.get_backend() == "nccl" else torch.device("cpu")
-        flag = torch.tensor([0 if blob is None else (2 if wk.arch.policy_attention else 1)], device=dev)
-        dist.broadcast(flag, src=0)
-        if not int(flag.item()):
-            return
+        n = None
         if rank != 0:
-            if int(flag.item()) == 2 and not wk.arch.policy_attention:
+            if flag == 2 and not wk.arch.policy_attention:
                 wk.arch = _model.transgo_arch()
             n = _model._lib.load().tg_net_blob_floats_arch(wk.S, wk.config.encode_state_channels, wk.filters, wk.arch.code.encode())
-            blob = np.zeros(n, np.float32)
-        wk.set_weights_blob(broadcast_weights(blob, src=0, device=dev), background=True)
+        got = broadcast_weights(blob, src=0, device=dev, n_floats=n)
+        # rank 0 already holds the host blob; the receiving ranks load what the broadcast left in their GPU memory, device -> device
+        wk.set_weights_blob(blob if rank == 0 else got, background=True)
+
+    def _refresh_weights(self, shared_storage_worker):
+        """self_play.py:913 alone (no throttle): see _move_prologue."""
+        self._move_prologue(shared_storage_worker, throttle=False)
 
     def policy_evaluate(self, n_games=10, shared_storage_worker=None, seed=0, evaluators=None):
         """New-vs-old evaluation matches (self_play.py:986-1040): the train model ("weights") against the evaluation model
@@ -430,7 +470,10 @@ class SelfPlay:
         (transgo_amd.distributed.gather_harvest: the RCCL exchange that replaces the per-tuple Ray RPCs of :956,:965) and only
         rank 0 appends.  `mem` is either a device store (DeviceReplayMemory: the batch goes HBM -> HBM) or anything with the
         reference's append(obs, pi, z, own) (replay_buffer.py:30-34), which receives the reference's 8 tuples per move in
-        the reference's order.  Counters: now_play_steps += 1 per move per game, now_play_games += 1 per finished game."""
+        the reference's order.  Counters: now_play_steps += 1 per move actually played (parked, finished and errored slots do
+        not count; summed over the ranks inside the gather's size exchange), now_play_games += 1 per finished game.
+        Collectives per move, all short and all entered by every rank together: the control word (_move_prologue), the
+        weight blob when one follows, the (games, positions, live) exchange and the payloads of gather_harvest."""
         from .distributed import gather_harvest
         dist, multi, rank, world = self._dist()
         owner = rank == 0
@@ -438,16 +481,17 @@ class SelfPlay:
         on_gpu = device_mem or (multi and dist.get_backend() == "nccl")
         wk = self.worker
         moves = 0
+        throttle = False                                  # the reference checks its ratio after a finished game only (:968-980)
         while max_moves is None or moves < max_moves:
             start = time.time()
-            self._refresh_weights(shared_storage_worker)
+            self._move_prologue(shared_storage_worker, throttle)
             h = wk.advance(device=on_gpu)
-            batches = gather_harvest(h, wk.S, wk.config.encode_state_channels, dst=0, device_index=wk.device) if multi \
-                else ([h] if h is not None else [])
+            batches, live = gather_harvest(h, wk.S, wk.config.encode_state_channels, dst=0, device_index=wk.device, live=wk.last_live)
             moves += 1
+            throttle = False
             if not owner:
                 continue
-            _bump(shared_storage_worker, "now_play_steps", wk.G * world)              # self_play.py:928
+            _bump(shared_storage_worker, "now_play_steps", live)                      # self_play.py:928
             finished = 0
             for hb in batches:
                 if device_mem:
@@ -457,13 +501,6 @@ class SelfPlay:
                         _call(mem.append, *tup)                                       # self_play.py:956, :965
                 finished += hb.n_games
             _bump(shared_storage_worker, "now_play_games", finished)                  # self_play.py:967
-            while (finished and                                                       # self_play.py:970-980
-                   _get(_call(shared_storage_worker.get_info, "now_train_steps"))
-                   / max(1, _get(_call(shared_storage_worker.get_info, "now_play_steps")))
-                   < _get(_call(shared_storage_worker.get_info, "train_play_ratio"))
-                   and _get(_call(shared_storage_worker.get_info, "adjust_train_play_ratio"))
-                   and _get(_call(shared_storage_worker.get_info, "now_play_games"))
-                   < _get(_call(shared_storage_worker.get_info, "game_total_num"))):
-                time.sleep(0.5)
+            throttle = finished > 0                       # waited for at the top of the next move, by all ranks together
             if finished:
                 print("run time:%.4fs" % (time.time() - start))

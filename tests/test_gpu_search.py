@@ -58,7 +58,8 @@ def test_reference_full_games(golden_dir, tag):
 
 
 @pytest.mark.parametrize("tag,full", [("sharp_s21_n48", True), ("flat_s22_n24", True), ("sharp_s23_n160", False),
-                                      ("sharp_s24_n800", False)])     # the last: BASELINE configs[3]'s 800 simulations/move
+                                      ("sharp_s24_n800", False),      # BASELINE configs[3]'s 800 simulations/move
+                                      ("sharp_s25_n1600", False)])    # BASELINE configs[4]'s 1600 simulations/move
 def test_reference_19x19_search(golden_dir, tag, full):
     """Board size 19 against vectors recorded from the reference WP_MCTS on a 19x19 build of its engine
     (tests/golden/gen_search19.py): visit counts, moves, pi, RNG position per move; final score / territory of full games."""

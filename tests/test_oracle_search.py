@@ -58,7 +58,8 @@ def test_deep_search(golden_dir, tag, moves):
 
 
 @pytest.mark.parametrize("tag,full", [("sharp_s21_n48", True), ("flat_s22_n24", True), ("sharp_s23_n160", False),
-                                      ("sharp_s24_n800", False)])     # BASELINE configs[3]: 800 simulations/move
+                                      ("sharp_s24_n800", False),      # BASELINE configs[3]: 800 simulations/move
+                                      ("sharp_s25_n1600", False)])    # BASELINE configs[4]: 1600 simulations/move
 def test_19x19_search_matches_reference(golden_dir, tag, full):
     """The same observables at board size 19, recorded from the reference WP_MCTS running on a 19x19 build of its engine
     (tests/golden/gen_search19.py): two games to the ply limit and one deeper search."""

@@ -523,14 +523,17 @@ template <int S> __device__ void encode_planes(BoardWave<S>& bw, const BoardStat
 // one 64-bit ballot (wave-uniform), and every lane assembles the output words it owns (w = lane, lane + 64, ...) from the ballots
 // that overlap them by shifts.  Other sizes OR the bits into an LDS image with atomics (up to 32 lanes per word: ~4x slower per
 // position, but 19x19 steps are dominated by the tower anyway).
+#ifndef TG_ENCODE_BALLOT19
+#define TG_ENCODE_BALLOT19 1
+#endif
 template <int S> __device__ void encode_bits(BoardWave<S>& bw, const BoardState<S>& st, const RulesCfg& cfg, uint32_t* lds,
                                              uint32_t* out) {
     using G = Geo<S>;
     uint32_t m[G::NW];
     encode_mask(bw, st, cfg, m);
     const int C = cfg.encode_dim, W = (C * G::P + 31) / 32;
-    if constexpr (S == 9) {
-        constexpr int WPL = ((13 * G::P + 31) / 32 + 63) / 64;      // output words per lane
+    if constexpr (S == 9 || TG_ENCODE_BALLOT19) {
+        constexpr int WPL = ((13 * G::P + 31) / 32 + 63) / 64;      // output words per lane (1 at 9x9, 3 at 19x19)
         uint32_t word[WPL];
 #pragma unroll
         for (int q = 0; q < WPL; ++q) word[q] = 0;

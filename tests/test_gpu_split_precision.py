@@ -1,0 +1,121 @@
+"""Opt-in split-precision network ("f32x3", net_precision 3): every conv operand of the tower is carried as fp16
+hi + lo, the four partial products (w_hi + w_lo)(a_hi + a_lo) run on the fp16 matrix cores with f32 accumulation, the residual
+stream, the narrow head conv and the dense heads stay f32.  ~22 significand bits per operand: the outputs must sit within 1e-5 of
+the fp32 torch tower (north_star allows 1e-3), and searches driven by it must agree with the oracle driving the torch network about
+as well as the exact-f32 path does.  The default path is untouched (tests/test_gpu_net.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _positions(S, n, seed):
+    rng = np.random.RandomState(seed)
+    x = np.zeros((n, 10, S, S), np.float32)
+    occ = rng.rand(n, S, S)
+    for c in range(3):
+        x[:, c] = (occ < 0.1 * (c + 1)) & (occ >= 0.1 * c)
+        x[:, 3 + c] = (occ > 1 - 0.1 * (c + 1)) & (occ <= 1 - 0.1 * c)
+    x[:, 6:] = rng.rand(n, 4, S, S) < 0.05
+    return x
+
+
+@pytest.mark.parametrize("S,F,NB,n", [(9, 128, 6, 600), (19, 256, 20, 4), (9, 256, 3, 40), (19, 128, 2, 3)])
+def test_split_precision_tower_within_1e5_of_torch_f32(S, F, NB, n):
+    """BASELINE configs[1]'s net (6 x 128 @ 9x9, several row tiles incl. a partial one) and configs[3]'s (20 x 256 @ 19x19)."""
+    import torch
+    from oracle.net import seeded_tower
+    from transgo_amd.model import HipNetwork
+    torch.set_num_threads(8)
+    net = seeded_tower(S, 10, F, NB, seed=4000 + NB)
+    x = _positions(S, n, 8)
+    with torch.no_grad():
+        p, v, o = [t.numpy() for t in net.main_prediction(torch.from_numpy(x))]
+    h = HipNetwork(S, 10, F, NB, rows_cap=max(8, n), precision="f32x3")
+    h.set_weights(net.get_weights())
+    hp, hv, ho = h.main_prediction(x)
+    e = [float(np.abs(a - b).max()) for a, b in ((hp, p), (hv, v), (ho, o))]
+    # the exact-f32 path on the same input, for scale
+    h32 = HipNetwork(S, 10, F, NB, rows_cap=max(8, n))
+    h32.set_weights(net.get_weights())
+    e32 = [float(np.abs(a - b).max()) for a, b in zip(h32.main_prediction(x), (p, v, o))]
+    print(f"f32x3 {NB}x{F}@{S}x{S}: max abs err vs torch f32 policy {e[0]:.2e} value {e[1]:.2e} own {e[2]:.2e} "
+          f"(exact-f32 MFMA path: {e32[0]:.2e} {e32[1]:.2e} {e32[2]:.2e})")
+    assert max(e) < TOL
+    assert np.allclose(hp.sum(1), 1.0, atol=1e-5)
+
+
+def test_split_precision_background_refresh_and_refusals():
+    """The weight hand-off (tg_net_load_async -> switch at a boundary) restages the split copies too; widths the fp16 kernels are not
+    built for are refused loudly."""
+    import ctypes
+    from transgo_amd import model
+    from transgo_amd._lib import TransgoError
+    from transgo_amd.model import HipNetwork
+    x = _positions(9, 20, 3)
+    sds = [model.random_weights(9, 10, 128, 2, seed=s) for s in (11, 12)]
+    want = []
+    for sd in sds:
+        h = HipNetwork(9, 10, 128, 2, rows_cap=32, precision="f32x3")
+        h.set_weights(sd)
+        want.append(h.main_prediction(x))
+        h.ctx.close()
+    h = HipNetwork(9, 10, 128, 2, rows_cap=32, precision="f32x3")
+    h.set_weights(sds[0])
+    blob = model.pack_weights(sds[1], 9, 10, 128, arch=h.arch)
+    h.ctx.call("tg_net_load_async", h.arch.code.encode(), blob.ctypes.data_as(ctypes.c_void_p), blob.size)
+    pend = ctypes.c_int(-1)
+    h.ctx.call("tg_net_load_poll", 1, ctypes.byref(pend))
+    assert pend.value == 0
+    assert all(np.array_equal(a, b) for a, b in zip(h.main_prediction(x), want[1]))
+    with pytest.raises(TransgoError):
+        HipNetwork(9, 10, 64, 2, rows_cap=8, precision="f32x3").set_weights(model.random_weights(9, 10, 64, 2))
+
+
+def test_split_precision_search_agrees_with_the_oracle():
+    """Whole engine with the split-precision tower against the CPU oracle driving the fp32 torch tower (same weights, same seeds),
+    as tests/test_gpu_selfplay.py::test_end_to_end_visit_counts_with_the_real_network does for the exact-f32 path: every game's
+    first move identical, and the great majority of all (game, move) visit-count vectors."""
+    import torch
+    from oracle.go_oracle import OracleGoEnv
+    from oracle.net import TowerNetwork
+    from oracle.wp_mcts import OracleSearch
+    from transgo_amd import model
+    from transgo_amd.engine import SelfPlayEngine
+    torch.set_num_threads(4)
+    G, sims, moves, F, NB = 12, 48, 4, 128, 2
+    sd = model.random_weights(9, 10, F, NB, seed=78)
+    net = TowerNetwork(9, 10, F, NB).eval()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+
+    def ev(obs):
+        with torch.no_grad():
+            p, v, _ = net.main_prediction(torch.from_numpy(obs))
+        return p.numpy(), v.numpy()
+    eng = SelfPlayEngine(G, num_simulation=sims, net_blocks=NB, net_filters=F, net_precision="f32x3")
+    model.load_into(eng.ctx, sd, 9, 10, F, NB)
+    seeds = np.arange(600, 600 + G)
+    eng.reset(seeds)
+    orcs = [OracleSearch(OracleGoEnv(), ev, np.random.RandomState(int(s)), num_simulation=sims) for s in seeds]
+    same, total, alive = 0, 0, np.ones(G, bool)
+    for m in range(moves):
+        eng.search()
+        vis, rn, pl, st, ob = eng.root_info()
+        acts, pis = eng.choose_moves(vis, st)
+        for g, o in enumerate(orcs):
+            if not alive[g]:
+                continue
+            a, pi, obs, info = o.search_move()
+            raw = np.array([o.root.kids[i].n if i in o.root.kids else 0 for i in range(82)])
+            ok = (raw == vis[g]).all() and a == acts[g]
+            total += 1; same += int(ok)
+            if m == 0:
+                assert ok, (g, "first move must match exactly")
+            if not ok:
+                alive[g] = False
+            else:
+                o.advance(a)
+        eng.play(acts)
+    print(f"f32x3: identical visit-count vectors {same}/{total}")
+    assert same >= 0.85 * total

@@ -25,7 +25,8 @@ class Config:
         self.stagger_games = 0                   # T > 1: slot g starts its first game at step g mod T (BatchedSelfPlay.start): games end
                                                  # spread over T steps instead of all on one; 0 = all slots start together
         self.inference_dtype = "f32"             # "f16": fp16 weights/activations, f32 accumulate (BASELINE config 5; towers of 128/256
-                                                 # filters); "f16r": the residual stream in fp16 as well (+4-6 %, error < 4e-4 over 40 blocks)
+                                                 # filters); "f16r": the residual stream in fp16 as well (+4-6 %, error < 4e-4 over 40 blocks);
+                                                 # "f32x3": split precision -- conv operands as fp16 hi + lo, f32 accumulate, ~1e-6 of f32
         self.batch_size = 2048
         self.train_play_ratio = 7500 / 100000    # configure.py:61
         self.adjust_train_play_ratio = True

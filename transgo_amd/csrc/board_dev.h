@@ -524,7 +524,7 @@ template <int S> __device__ void encode_planes(BoardWave<S>& bw, const BoardStat
 // that overlap them by shifts.  Other sizes OR the bits into an LDS image with atomics (up to 32 lanes per word: ~4x slower per
 // position, but 19x19 steps are dominated by the tower anyway).
 #ifndef TG_ENCODE_BALLOT19
-#define TG_ENCODE_BALLOT19 1
+#define TG_ENCODE_BALLOT19 0
 #endif
 template <int S> __device__ void encode_bits(BoardWave<S>& bw, const BoardState<S>& st, const RulesCfg& cfg, uint32_t* lds,
                                              uint32_t* out) {

@@ -6,6 +6,7 @@
 // expansion, value backup).  Between the two the batch is evaluated by the network (net.hip) or, for parity tests,
 // by values injected through tg_sp_set_eval.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -17,6 +18,19 @@
 using namespace tg;
 
 namespace {
+
+// In-kernel phase stamps of k_collect (diagnostic builds only: -DTG_TREE_STAMP; scripts/stamp_tree.py prints them).
+#ifdef TG_TREE_STAMP
+__device__ unsigned long long g_stamp[16];
+#define TG_ST_DECL unsigned long long st_t = __builtin_amdgcn_s_memtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long st_t0 = st_t
+#define TG_ST(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[i] += n_ - st_t; st_t = n_; } while (0)
+#define TG_ST_FLUSH() do { if (lane == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_stamp[i_], st_acc[i_]); \
+                            atomicAdd(&g_stamp[8], __builtin_amdgcn_s_memtime() - st_t0); atomicAdd(&g_stamp[9], 1ull); } } while (0)
+#else
+#define TG_ST_DECL
+#define TG_ST(i)
+#define TG_ST_FLUSH()
+#endif
 
 // ---- device helpers -------------------------------------------------------------------------------------------------------
 constexpr int kMaxPath = 512;                        // longest selection path kept in LDS (>= SearchCfg::maxd, checked at create)
@@ -198,6 +212,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
     int npaths = 0, err = 0;
     int leafs[8], rows[8];
     unsigned long long sims = 0, depth_sum = 0, evals = 0, child_sum = 0;
+    TG_ST_DECL;
 
     for (int attempt = 0; attempt < 2 * sc.R && npaths < sc.R && !err; ++attempt) {    // self_play.py:616
         int* path = paths + npaths * sc.maxd;
@@ -254,6 +269,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
         if (depth == 0) err |= 8;                                      // root must be expanded before searching
         if (err) break;
         depth_sum += depth;
+        TG_ST(0);
         // ---- leaf ----
         const int len = depth + 1;
         if (cur.term) {                                                // cached terminal result
@@ -262,6 +278,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
             for (int dd = lane; dd < len; dd += 64) backup_node(&arena[path_s[dd]], ((len - 1 - dd) & 1) ? -v : v);
             __syncthreads();
             ++sims;
+            TG_ST(2);
             continue;
         }
         int row = -1;
@@ -273,6 +290,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
             BoardState<S> st = hdr_of<S>(arena, pblk)->st;            // the parent's position
             bool ok;
             const bool done = state_step(bw, st, cur.action, d.rules, /*check=*/false, &ok);   // self_play.py:629
+            TG_ST(1);
             if (done) {                                                // self_play.py:638-642
                 const float raw = tromp_taylor(bw, st, nullptr);
                 const int winner = (raw - d.rules.komi > 0.f) ? kBlack : kWhite;              // environment.py:118-119
@@ -282,15 +300,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
                 for (int dd = lane; dd < len; dd += 64) backup_node(&arena[path_s[dd]], ((len - 1 - dd) & 1) ? -v : v);
                 __syncthreads();
                 ++sims;
+                TG_ST(2);
                 continue;
             }
             const bool fits = free_slot + HS + G::A <= sc.arena_slots;  // room for the largest possible block
             if (!fits) { err |= 1; break; }
             bw.load_colors(st.bb[0], st.bb[1]);
             bw.analyze();
+            TG_ST(3);
             const int blk = make_block(bw, st, arena, free_slot, sc.arena_slots, true);
+            TG_ST(4);
             row = nslot++;                                             // the game's own next slot: no allocation, no atomic
             encode_bits(bw, st, d.rules, bits_s, d.obs_bits + ((size_t)g * sc.R + row) * d.obs_words);   // self_play.py:798
+            TG_ST(5);
             if (lane == 0) {
                 arena[node].block = blk;
                 arena[node].flags |= F_PSEUDO;
@@ -303,7 +325,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
         if (lane == 0) { d.path_len[(size_t)g * sc.R + npaths] = len; d.path_row[(size_t)g * sc.R + npaths] = row; }
         __syncthreads();
         ++npaths;
+        TG_ST(6);
     }
+    TG_ST_FLUSH();
     if (lane == 0) {
         d.game_nslot[g] = nslot;
         c->n_paths = npaths; c->free_slot = free_slot; c->error |= err;
@@ -612,11 +636,17 @@ __global__ __launch_bounds__(1024) void k_compact(EngineDev d, int R, int count_
     if (tid == 0) { d.counters[CNT_ROWS] = part[1023]; if (count_active) d.counters[CNT_ACTIVE] = act_s; }
 }
 
+// TG_TRACE_LAUNCH=1 in the environment: every tree-kernel launch is announced on stderr and waited for, so that a GPU fault is
+// reported right behind the name of the kernel that caused it (diagnostic aid; off = no cost beyond one static read)
+static const bool g_trace_launch = getenv("TG_TRACE_LAUNCH") && atoi(getenv("TG_TRACE_LAUNCH")) != 0;
+static long g_trace_seq = 0;
 #define TG_LAUNCH(ctx, kern, grid, ...)                                                                   \
     do {                                                                                                  \
+        if (g_trace_launch) { fprintf(stderr, "[tg %ld] %s<%d> grid %d\n", ++g_trace_seq, #kern, (ctx)->S, (int)(grid)); fflush(stderr); } \
         if ((ctx)->S == 9) hipLaunchKernelGGL(kern<9>, dim3(grid), dim3(64), 0, (ctx)->stream, __VA_ARGS__); \
         else hipLaunchKernelGGL(kern<19>, dim3(grid), dim3(64), 0, (ctx)->stream, __VA_ARGS__);             \
         TG_HIP(ctx, hipGetLastError());                                                                   \
+        if (g_trace_launch) TG_HIP(ctx, hipStreamSynchronize((ctx)->stream));                             \
     } while (0)
 
 int read_counters(tg_ctx* ctx, int32_t* out) {
@@ -765,6 +795,7 @@ int tg_sp_reset(tg_ctx* ctx, const uint32_t* seeds, const uint8_t* mask) {
         TG_HIP(ctx, hipMemcpyAsync(e->d_u8, mask, G, hipMemcpyHostToDevice, ctx->stream));
         d_mask = e->d_u8;
     }
+    if (g_trace_launch) { fprintf(stderr, "[tg %ld] k_reset<%d> grid %d (masked %d)\n", ++g_trace_seq, ctx->S, G, mask ? 1 : 0); fflush(stderr); }
     if (ctx->S == 9) hipLaunchKernelGGL(k_reset<9>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<9>*)nullptr);
     else hipLaunchKernelGGL(k_reset<19>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<19>*)nullptr);
     TG_HIP(ctx, hipGetLastError());
@@ -949,7 +980,11 @@ int tg_sp_search(tg_ctx* ctx, int32_t* n_waves) {
         int32_t active = 0, rows = 0;
         int rc = tg_sp_collect(ctx, &active, &rows);
         if (rc) return rc;
-        if (rows > 0) { rc = tg_net_forward(ctx, rows); if (rc) return rc; ctx->eng->batch_ready = true; }
+        if (rows > 0) {
+            if (g_trace_launch) { fprintf(stderr, "[tg %ld] network forward, %d rows\n", ++g_trace_seq, rows); fflush(stderr); }
+            rc = tg_net_forward(ctx, rows); if (rc) return rc; ctx->eng->batch_ready = true;
+            if (g_trace_launch) TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
         rc = tg_sp_absorb(ctx);
         if (rc) return rc;
         if (active == 0) break;
@@ -1170,6 +1205,15 @@ int tg_prof_read_tree(tg_ctx* ctx, double* collect_ms, double* absorb_ms, int64_
     }
     return TG_OK;
 }
+
+#ifdef TG_TREE_STAMP
+// diagnostic builds: summed s_memtime cycles per k_collect phase [0..7], whole-kernel cycles [8], game-waves [9]; reset = 1 clears
+int tg_debug_tree_stamps(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 16) != hipSuccess) return TG_ERR_HIP;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)) != hipSuccess) return TG_ERR_HIP; }
+    return TG_OK;
+}
+#endif
 
 int tg_prof_enable_tree(tg_ctx* ctx, int on, int max_waves) {
     NEED_ENGINE(ctx);

@@ -41,7 +41,9 @@ struct Net {
     float* bufQ = nullptr; float* hca = nullptr;   // q|k|v projections [rows][P][1.5F]; policy head conv output
     float* bufAct = nullptr;                       // pre-activated input of the next conv (DMA path)
     int* tile_ctr = nullptr;                       // [2*NB] tile counters of the persistent conv launches (zeroed per forward)
-    int prec = 0;                                  // cfg.net_precision: 0 = f32, 1 = fp16 storage + f32 accumulate (k_conv3x3_h2), 2 = 1 + fp16 residual stream
+    int prec = 0;                                  // cfg.net_precision: 0 = f32, 1 = fp16 storage + f32 accumulate (k_conv3x3_h2), 2 = 1 + fp16 residual stream,
+                                                   // 3 = split precision ("f32x3"): every operand as fp16 hi + lo, all four products on the fp16 MFMA, f32 accumulate
+    float* wsc = nullptr;                          // prec 3: [2*NB + 1] power-of-two factor 2^-s each conv's weights were scaled by before splitting (stem last)
     _Float16* stem_h = nullptr; _Float16* head_h = nullptr; _Float16* x0h = nullptr;   // fp16 path: stem [2*9][F][32] (16 planes padded to 64), head [F/32*9][16][32], input [rows][P][64]
     _Float16* wh = nullptr; _Float16* act16 = nullptr; _Float16* h16 = nullptr;   // fp16 path: weights [2*NB][F/32*9][F][32], activations [rows][P][F]
     int dma = 0;                                   // attention-free F=128/256 f32 tower: 1 = k_conv3x3_sg chain (default), 0 = k_conv3x3 (TG_DMA_CONV=0)
@@ -58,7 +60,8 @@ struct Net {
     // fields above are bound to it); a refresh fills the other one -- tg_net_load_async on a side stream while searches keep
     // running -- and the next forward that finds it complete rebinds.  `swapped` orders a later refill of the retired set behind
     // every kernel that may still read it.
-    struct WeightSet { float* blob = nullptr; float* wstage = nullptr; _Float16* wh = nullptr; _Float16* stem_h = nullptr; _Float16* head_h = nullptr; };
+    struct WeightSet { float* blob = nullptr; float* wstage = nullptr; _Float16* wh = nullptr; _Float16* stem_h = nullptr; _Float16* head_h = nullptr;
+                       float* wsc = nullptr; };
     WeightSet sets[2]; int active = 0; bool pending = false;
     hipStream_t side = nullptr; hipEvent_t loaded = nullptr, swapped = nullptr; float* pinned = nullptr;
     // profiling of the dominant kernel (3x3 conv F->F) with HIP events on the launch stream
@@ -515,10 +518,16 @@ __device__ __forceinline__ void vmcnt_uniform(int n) {
 // the 8 CONSECUTIVE couts u * 32 + kq * 8 .. + 7 of its row -- one whole 16-B chunk of the chunk-major fp16 tensors.  Every fp16
 // access of the epilogue (and the fp16 residual read that starts the accumulators) is one 16-B access per lane instead of two
 // 8-B ones: half the memory instructions on the path that the DMA pieces already load.
-template <int F, int CT, int NPT, int EPI, bool R16>
+// X2 (split precision, net_precision 3): the accumulators hold the conv of weights scaled by 2^s (wsc = 2^-s undoes it, exactly),
+// and every fp16 output is written as TWO chunks -- hi = half(v), lo = half(v - hi) -- at the [16 hi | 16 lo] positions of the
+// channel group (x2_index), which is what the next conv's K = 32 MFMA step consumes.
+__device__ __forceinline__ int x2_index(int c) { return ((c >> 4) << 5) + (c & 15); }       // hi position of real channel c; lo = + 16
+template <int F, int CT, int NPT, int EPI, bool R16, bool X2 = false>
 __device__ __forceinline__ void conv_epilogue_h8(f32x4 (&acc)[CT][NPT], const int (&mrow)[NPT], int M, int co_base, int kq,
-                                                 float* __restrict__ out32, _Float16* __restrict__ out16, const float* par, int pstride) {
+                                                 float* __restrict__ out32, _Float16* __restrict__ out16, const float* par, int pstride,
+                                                 float wsc = 1.f) {
     static_assert(CT % 2 == 0, "tile pairs");
+    static_assert(!(X2 && R16), "split precision keeps the f32 residual stream");
 #pragma unroll
     for (int t = 0; t < NPT; ++t) {
         if (mrow[t] >= M) continue;
@@ -527,8 +536,41 @@ __device__ __forceinline__ void conv_epilogue_h8(f32x4 (&acc)[CT][NPT], const in
             const int lc = u * 32 + kq * 8, col = co_base + lc;
             f32x4 v[2];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) v[h] = acc[2 * u + h][t] + *reinterpret_cast<const f32x4*>(par + lc + 4 * h);
+            for (int h = 0; h < 2; ++h) v[h] = (X2 ? acc[2 * u + h][t] * wsc : acc[2 * u + h][t]) + *reinterpret_cast<const f32x4*>(par + lc + 4 * h);
             h8 o;
+            if constexpr (X2) {
+                auto store_split = [&](const f32x4 (&w)[2]) {
+                    h8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float x = w[e >> 2][e & 3]; hi[e] = (_Float16)x; lo[e] = (_Float16)(x - (float)hi[e]); }
+                    const int c2 = x2_index(col);
+                    *reinterpret_cast<h8*>(out16 + h16_index(mrow[t], c2, M)) = hi;
+                    *reinterpret_cast<h8*>(out16 + h16_index(mrow[t], c2 + 16, M)) = lo;
+                };
+                if (EPI == 0 || EPI == 4) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[h][e] = v[h][e] > 0.f ? v[h][e] : 0.f;
+                }
+                if (EPI == 0) { store_split(v); continue; }
+                if (out32) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) *reinterpret_cast<f32x4*>(out32 + (size_t)mrow[t] * F + col + 4 * h) = v[h];
+                }
+                if (out16) {
+                    f32x4 w[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(par + pstride + lc + 4 * h);
+                        const f32x4 sh = *reinterpret_cast<const f32x4*>(par + 2 * pstride + lc + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float y = v[h][e] * sc[e] + sh[e]; w[h][e] = y > 0.f ? y : 0.f; }
+                    }
+                    store_split(w);
+                }
+                continue;
+            }
             if (EPI == 0) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float w = v[e >> 2][e & 3]; o[e] = (_Float16)(w > 0.f ? w : 0.f); }
@@ -574,11 +616,19 @@ __device__ __forceinline__ void conv_epilogue_h8(f32x4 (&acc)[CT][NPT], const in
 // reads chip-wide at 1 PFLOP/s).  Measured shares of a 0.88-ms launch (8192 boards, F=256; ablation builds): MFMA loop alone
 // 0.44, DMA issue + traffic 0.17, epilogue 0.22, B-fragment addressing + reads 0.09, barriers 0.03, A reads 0.03.
 // An 8-wave 256x256 tile with one workgroup per CU (64-channel stages) measured 827 vs 888 TFLOP/s for this shape.
-template <int S, int CIN, int F, int EPI, bool R16 = false>
+// X2 = split precision (net_precision 3, "f32x3"): the tensors hold every real channel as fp16 hi + lo, a 32-wide channel group
+// being [16 real channels hi | the same 16 lo] in activations and weights alike (CIN counts those positions: 2 x the real input
+// channels).  One K = 32 MFMA step with the B fragment [a_hi | a_lo] against the A fragment [w_hi | w_hi] gives w_hi*(a_hi + a_lo),
+// a second one against [w_lo | w_lo] gives w_lo*(a_hi + a_lo): all four products of (w_hi + w_lo)(a_hi + a_lo) in f32
+// accumulation from ONE read of the activations and two reads of the SAME weight tile (lane (j, kq) takes 16-B chunk kq & 1 of
+// row j for the hi fragment, 2 + (kq & 1) for the lo one -- no duplicate storage, the swizzle and its conflict-freedom carry
+// over).  4 x the MFMA work of the plain fp16 conv at ~22 significand bits per operand, against 16 x for the exact-f32 MFMA.
+template <int S, int CIN, int F, int EPI, bool R16 = false, bool X2 = false>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restrict__ in, float* __restrict__ out32,
                                                        _Float16* __restrict__ out16, const float* __restrict__ res,
                                                        const _Float16* __restrict__ Ws, const float* __restrict__ bias,
-                                                       const float* __restrict__ s2, const float* __restrict__ t2, int M, int nblk) {
+                                                       const float* __restrict__ s2, const float* __restrict__ t2, int M, int nblk,
+                                                       const float* __restrict__ wsc_p = nullptr) {
     constexpr int P = S * S, HALO = S + 1, KC = 32, NW = 4, NPT = 4, TM = 64 * NW, NCO = 128, CT = NCO / 16, COS = F / NCO;
     constexpr int NCHK = KC / 8, RPP = 64 / NCHK;                       // 4 chunks per 64-B row, 16 rows per 1-KB DMA piece
     constexpr int NSL = CIN / KC, NST = NSL * 9, NPAIR = NST / 2, NSLOT = 4;        // CIN input channels (row stride), F output channels
@@ -642,7 +692,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
     };
     prologue();
     bool first = true;
-    const int aoff = j * KC + ((kq ^ swz64(j)) << 3);                    // A fragment of cout tile ct: + ct*16*KC
+    const int aoff = j * KC + (((X2 ? (kq & 1) : kq) ^ swz64(j)) << 3);   // A fragment of cout tile ct: + ct*16*KC (X2: the hi half)
+    const int aoff_lo = j * KC + (((2 + (kq & 1)) ^ swz64(j)) << 3);      // X2: the lo half of the same rows
+    const float wsc = X2 ? wsc_p[0] : 1.f, wsc_inv = X2 ? 1.f / wsc : 1.f;   // powers of two: both exact
     for (;;) {
         unsigned vmask[NPT]; int vrow[NPT];
 #pragma unroll
@@ -693,6 +745,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
                         }
                     } else {
                         acc[ct][t] = *reinterpret_cast<const f32x4*>(res + (size_t)mc * F + co0 + (ct >> 1) * 32 + kq * 8 + (ct & 1) * 4);
+                        if (X2) acc[ct][t] = acc[ct][t] * wsc_inv;              // the accumulators run in the scaled-weight domain
                     }
                 }
             }
@@ -714,24 +767,28 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
 
 #pragma unroll 1                                                         // unrolled, hipcc keeps 4 pairs of address state live and spills
         for (int pp = 0; pp < NPAIR; ++pp) {
-            constexpr int NU = 2 * CT, DA = 4;
+            constexpr int SPS = X2 ? 2 * CT : CT;                        // MFMA steps per stage (X2: hi and lo fragment of every cout tile)
+            constexpr int NU = 2 * SPS, DA = 4;
             const int g0 = 2 * pp;
             // A fragments run DA-1 steps ahead of their MFMAs (a step = 4 MFMAs = 64 cycles; an LDS read under load takes longer)
+            auto a_addr = [&](int un) -> const _Float16* {
+                const int st = un / SPS, w = un % SPS;
+                const int ct = X2 ? w >> 1 : w;
+                return ws[(g0 + st) % NSLOT] + ct * 16 * KC + ((X2 && (w & 1)) ? aoff_lo : aoff);
+            };
             f32x4 a[DA];
 #pragma unroll
-            for (int u = 0; u < DA - 1; ++u) a[u] = *reinterpret_cast<const f32x4*>(ws[(g0 + u / CT) % NSLOT] + (u % CT) * 16 * KC + aoff);
+            for (int u = 0; u < DA - 1; ++u) a[u] = *reinterpret_cast<const f32x4*>(a_addr(u));
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
-                if (u + DA - 1 < NU) {
-                    const int un = u + DA - 1;
-                    a[un % DA] = *reinterpret_cast<const f32x4*>(ws[(g0 + un / CT) % NSLOT] + (un % CT) * 16 * KC + aoff);
-                }
-                if (u % CT == CT / 2 && g0 + u / CT + 1 < NST) read_b(b_next, g0 + u / CT + 1);   // that stage's slab is visible (see below)
+                if (u + DA - 1 < NU) a[(u + DA - 1) % DA] = *reinterpret_cast<const f32x4*>(a_addr(u + DA - 1));
+                if (u % SPS == SPS / 2 && g0 + u / SPS + 1 < NST) read_b(b_next, g0 + u / SPS + 1);   // that stage's slab is visible (see below)
+                const int ct = X2 ? (u % SPS) >> 1 : u % SPS;
 #pragma unroll
                 for (int t = 0; t < NPT; ++t)
-                    acc[u % CT][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a[u % DA]), __builtin_bit_cast(h8, b_cur[t]),
-                                                                            acc[u % CT][t], 0, 0, 0);
-                if (u % CT == CT - 1) {
+                    acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a[u % DA]), __builtin_bit_cast(h8, b_cur[t]),
+                                                                        acc[ct][t], 0, 0, 0);
+                if (u % SPS == SPS - 1) {
 #pragma unroll
                     for (int t = 0; t < NPT; ++t) b_cur[t] = b_next[t];
                 }
@@ -759,7 +816,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
         while (nb < nblk && tile_m0(nb) >= M) nb += gridDim.x;
         const bool have_next = nb < nblk;
         if (have_next) { bid = nb; m0 = tile_m0(nb); prologue(); }
-        conv_epilogue_h8<F, CT, NPT, (EPI == 1 ? 2 : EPI), R16>(acc, mrow, M, co0, kq, out32, out16, par, NCO);   // EPI 4: the stem
+        conv_epilogue_h8<F, CT, NPT, (EPI == 1 ? 2 : EPI), R16, X2>(acc, mrow, M, co0, kq, out32, out16, par, NCO, wsc);   // EPI 4: the stem
         if (!have_next) break;
     }
 }
@@ -779,6 +836,41 @@ __global__ __launch_bounds__(256) void k_restage_half(const float* __restrict__ 
         // pair8 (k_conv3x3_h2): destination row r of a 32-row group holds physical cout ((r & 15) >> 2) * 8 + ((r >> 4) & 1) * 4 + (r & 3)
         if (pair8) co = (co & ~31) | ((((co & 15) >> 2) << 3) + (((co >> 4) & 1) << 2) + (co & 3));
         dst[i] = ci < cin_src ? (_Float16)w[((size_t)tap * COUT + co) * cin_src + ci] : (_Float16)0.f;
+    }
+}
+
+// Split precision (net_precision 3).  k_absmax: largest |w| of one conv as float bits (non-negative floats order like unsigned ints).
+__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ w, size_t n, unsigned* __restrict__ out) {
+    unsigned m = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const unsigned b = __float_as_uint(w[i]) & 0x7fffffffu;
+        m = b > m ? b : m;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = __shfl_xor(m, o); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+// stage-ordered split copy: dst[(slice*9 + tap)][cout][32] = [16 channels hi | the same 16 lo] of w * 2^s, slice = 16 real input
+// channels (zero beyond cin_src), hi = half(v), lo = half(v - hi); s puts the conv's largest weight in [2^14, 2^15), so that the
+// lo halves of all but negligible weights are normal fp16 numbers; wsc_out = 2^-s for the epilogue.  pair8 as in k_restage_half.
+__global__ __launch_bounds__(256) void k_restage_split(const float* __restrict__ w, _Float16* __restrict__ dst, float* __restrict__ wsc_out,
+                                                       const unsigned* __restrict__ maxbits, int COUT, int cin_src, int nsl_dst, int pair8) {
+    const unsigned mb = maxbits[0];
+    int sh = mb ? 14 - ((int)((mb >> 23) & 0xffu) - 127) : 0;
+    sh = sh < -60 ? -60 : sh > 60 ? 60 : sh;
+    const float scale = ldexpf(1.f, sh);
+    if (blockIdx.x == 0 && threadIdx.x == 0) wsc_out[0] = ldexpf(1.f, -sh);
+    const size_t total = (size_t)nsl_dst * 9 * COUT * 32;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int k = (int)(i & 31);
+        const size_t r = i >> 5;
+        int co = (int)(r % COUT);
+        const int st = (int)(r / COUT);
+        const int sl = st / 9, tap = st % 9;
+        const int ci = sl * 16 + (k & 15);
+        if (pair8) co = (co & ~31) | ((((co & 15) >> 2) << 3) + (((co >> 4) & 1) << 2) + (co & 3));
+        const float v = ci < cin_src ? w[((size_t)tap * COUT + co) * cin_src + ci] * scale : 0.f;
+        const _Float16 hi = (_Float16)v;
+        dst[i] = (k & 16) ? (_Float16)(v - (float)hi) : hi;
     }
 }
 
@@ -1224,6 +1316,44 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
     }
     float* x = n->bufA; float* y = n->bufB;
     if constexpr (F == 128 || F == 256) {
+        if (n->prec == 3) {
+            // Split-precision chain ("f32x3"): the f32 tower's arithmetic with every conv operand carried as fp16 hi + lo and all
+            // four partial products on the fp16 matrix cores (k_conv3x3_h2<..., X2>): stem and tower convs; the residual stream
+            // stays f32 row-major, the narrow head conv and the dense heads are the f32 kernels.  Opt-in: not the default path.
+            if ((long long)M * F * 4 >= (1ll << 31)) TG_FAIL(ctx, TG_ERR_ARG, "split-precision path: rows * P * F * 4 bytes must stay below 2 GiB per activation buffer");
+            const int grid_h = (M + 255) / 256;
+            constexpr int COS = F / 128;
+            const int nblk_h2 = COS == 1 ? grid_h : (grid_h + 7) / 8 * 8 * COS;
+            const size_t nb = n->blocks.size();
+            int g0h = (int)(((size_t)M * 64 + 255) / 256); if (g0h > 65535) g0h = 65535;
+            if (n->in_bits) hipLaunchKernelGGL((k_bits_to_rows_h<S>), dim3(g0h), dim3(256), 0, st, n->in_bits, n->in_slot, n->x0h, rows, n->C, n->in_words);
+            else hipLaunchKernelGGL((k_obs_to_rows_h<S>), dim3(g0h), dim3(256), 0, st, obs, n->x0h, rows, n->C);
+            const float* wsc = n->wsc;
+            hipLaunchKernelGGL((k_conv3x3_h2<S, 64, F, 4, false, true>), dim3(nblk_h2), dim3(256), 0, st, (const _Float16*)n->x0h, x, n->act16,
+                               (const float*)nullptr, (const _Float16*)n->stem_h, n->stem.b, nb ? n->blocks[0].s1 : n->s_end,
+                               nb ? n->blocks[0].t1 : n->t_end, M, nblk_h2, wsc + 2 * nb);
+            for (size_t i = 0; i < nb; ++i) {
+                const BlockW& b = n->blocks[i];
+                const bool last = i + 1 == nb;
+                const float* sn = last ? nullptr : n->blocks[i + 1].s1;
+                const float* tn = last ? nullptr : n->blocks[i + 1].t1;
+                { ProfScope ps(n, st, conv_flops);
+                  hipLaunchKernelGGL((k_conv3x3_h2<S, 2 * F, F, 0, false, true>), dim3(nblk_h2), dim3(256), 0, st, (const _Float16*)n->act16,
+                                     (float*)nullptr, n->h16, (const float*)nullptr, b.h1, b.c1.b, (const float*)nullptr, (const float*)nullptr, M, nblk_h2,
+                                     wsc + 2 * i); }
+                { ProfScope ps(n, st, conv_flops);
+                  hipLaunchKernelGGL((k_conv3x3_h2<S, 2 * F, F, 1, false, true>), dim3(nblk_h2), dim3(256), 0, st, (const _Float16*)n->h16,
+                                     y, last ? (_Float16*)nullptr : n->act16, (const float*)x, b.h2, b.c2.b, sn, tn, M, nblk_h2, wsc + 2 * i + 1); }
+                float* t = x; x = y; y = t;
+            }
+            // the head conv is 16 couts wide (one MFMA tile): the f32 kernel reads the f32 residual stream and activates while staging
+            hipLaunchKernelGGL((k_conv3x3<S, F, 16, true, 0>), dim3(grid), dim3(256), 0, st, (const float*)x, n->hc,
+                               (const float*)nullptr, n->head.w, n->head.b, n->s_end, n->t_end, M);
+            hipLaunchKernelGGL((k_heads<S>), dim3((rows + HeadRows<S>::N - 1) / HeadRows<S>::N), dim3(256), 0, st, (const float*)n->hc, (const float*)n->hc, n->w_vo, n->b_vo,
+                               n->w_v, n->b_v, n->w_o, n->b_o, n->w_a, n->b_a, policy, value, own, rows);
+            TG_HIP(ctx, hipGetLastError());
+            return TG_OK;
+        }
         if (n->prec >= 1) {
             // fp16 chain: every conv (stem, tower, head conv) takes fp16 operands and accumulates in f32; the small dense heads
             // (k_heads) stay f32, and so does the residual stream x/y unless net_precision is 2 (then x/y are fp16, slice-major, and
@@ -1457,7 +1587,7 @@ size_t expected_floats(int S, int C, int F, const std::string& arch) {
 void bind_weights(Net* n, int k) {
     const int F = n->F; const size_t P = n->P, A = n->A, Wq = (size_t)F / 4 * 2 + F;
     const Net::WeightSet& w = n->sets[k];
-    n->blob = w.blob; n->wstage = w.wstage; n->wh = w.wh; n->stem_h = w.stem_h; n->head_h = w.head_h;
+    n->blob = w.blob; n->wstage = w.wstage; n->wh = w.wh; n->stem_h = w.stem_h; n->head_h = w.head_h; n->wsc = w.wsc;
     std::string trunk; bool pol = false;
     parse_arch(n->arch, &trunk, &pol);
     const float* p = w.blob;
@@ -1476,7 +1606,8 @@ void bind_weights(Net* n, int k) {
             b.c1.w = take(per); b.c1.b = take(F);
             b.c2.w = take(per); b.c2.b = take(F);
             b.g1 = w.wstage ? w.wstage + (size_t)(2 * ri) * per : nullptr; b.g2 = w.wstage ? w.wstage + (size_t)(2 * ri + 1) * per : nullptr;
-            b.h1 = w.wh ? w.wh + (size_t)(2 * ri) * per : nullptr; b.h2 = w.wh ? w.wh + (size_t)(2 * ri + 1) * per : nullptr;
+            const size_t perh = n->prec == 3 ? 2 * per : per;           // split precision: hi + lo halves of every weight
+            b.h1 = w.wh ? w.wh + (size_t)(2 * ri) * perh : nullptr; b.h2 = w.wh ? w.wh + (size_t)(2 * ri + 1) * perh : nullptr;
             L.ridx = ri++;
         } else {
             take_att(L.a);
@@ -1502,7 +1633,27 @@ int fill_weight_set(tg_ctx* ctx, Net* n, int k, const float* blob, hipStream_t s
     }
     Net view = *n;                                        // pointer fields of set k without disturbing the live binding
     bind_weights(&view, k);
-    if (n->prec >= 1) {
+    if (n->prec == 3) {
+        // split copies (hi | lo of w * 2^s per conv), made on the device from the blob just uploaded; the scale words double as the
+        // scratch of the abs-max reduction (bit patterns), overwritten with 2^-s by the restaging kernel that follows in order
+        const size_t nconv = 2 * view.blocks.size() + 1;
+        unsigned* mx = reinterpret_cast<unsigned*>(n->sets[k].wsc) + nconv;          // second half of the allocation
+        TG_HIP(ctx, hipMemsetAsync(mx, 0, sizeof(unsigned) * nconv, st));
+        size_t ci = 0;
+        for (const BlockW& b : view.blocks) {
+            for (int h = 0; h < 2; ++h) {
+                const float* w = h ? b.c2.w : b.c1.w;
+                hipLaunchKernelGGL(k_absmax, dim3(256), dim3(256), 0, st, w, (size_t)9 * F * F, mx + ci);
+                hipLaunchKernelGGL(k_restage_split, dim3(1024), dim3(256), 0, st, w, const_cast<_Float16*>(h ? b.h2 : b.h1), n->sets[k].wsc + ci,
+                                   (const unsigned*)(mx + ci), F, F, F / 16, 1);
+                ++ci;
+            }
+        }
+        hipLaunchKernelGGL(k_absmax, dim3(64), dim3(256), 0, st, view.stem.w, (size_t)9 * F * 16, mx + ci);
+        hipLaunchKernelGGL(k_restage_split, dim3(256), dim3(256), 0, st, view.stem.w, view.stem_h, n->sets[k].wsc + ci, (const unsigned*)(mx + ci),
+                           F, 16, 2, 1);                                              // 16 planes = one group, padded to two (an even stage count)
+        TG_HIP(ctx, hipGetLastError());
+    } else if (n->prec >= 1) {
         // stage-ordered fp16 copies, converted on the device from the blob just uploaded (round to nearest even)
         for (const BlockW& b : view.blocks) {
             hipLaunchKernelGGL(k_restage_half, dim3(1024), dim3(256), 0, st, b.c1.w, const_cast<_Float16*>(b.h1), F, F, F, 32, 1);   // k_conv3x3_h2: 32-channel stages, paired couts
@@ -1568,13 +1719,13 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
     if (e->rows_cap > rows_cap) rows_cap = e->rows_cap;
     Net* n = e->net;
     const int prec = ctx->cfg.net_precision;
-    if (prec < 0 || prec > 2) TG_FAIL(ctx, TG_ERR_ARG, "net_precision: 0 (f32), 1 (fp16 storage, f32 accumulate, f32 residual stream) or 2 (fp16 residual stream too)");
+    if (prec < 0 || prec > 3) TG_FAIL(ctx, TG_ERR_ARG, "net_precision: 0 (f32), 1 (fp16 storage, f32 accumulate, f32 residual stream), 2 (fp16 residual stream too) or 3 (split precision: fp16 hi + lo operands, f32 accumulate)");
     if (n && (n->rows_cap < rows_cap || n->arch != arch || n->prec != prec)) { tg_net_destroy(ctx); n = nullptr; }
     const size_t P = (size_t)S * S, A = P + 1, Wq = (size_t)F / 4 * 2 + F;
     const bool any_att = pol || trunk.find('A') != std::string::npos;
     int NB = 0; for (char c : trunk) NB += c == 'R';
     if (prec >= 1 && (any_att || (F != 128 && F != 256)))
-        TG_FAIL(ctx, TG_ERR_ARG, "net_precision 1 / 2 (fp16) is built for attention-free towers with 128 or 256 filters");
+        TG_FAIL(ctx, TG_ERR_ARG, "net_precision 1 / 2 / 3 (fp16 matrix cores) is built for attention-free towers with 128 or 256 filters");
     if (!n) {
         n = new Net();
         e->net = n;
@@ -1600,14 +1751,15 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
             TG_HIP(ctx, hipMalloc((void**)&w.blob, sizeof(float) * n_floats));
             if (n->dma) TG_HIP(ctx, hipMalloc((void**)&w.wstage, sizeof(float) * wcopy));
             if (prec >= 1) {
-                TG_HIP(ctx, hipMalloc((void**)&w.wh, sizeof(_Float16) * wcopy));
+                TG_HIP(ctx, hipMalloc((void**)&w.wh, sizeof(_Float16) * wcopy * (prec == 3 ? 2 : 1)));
+                if (prec == 3) TG_HIP(ctx, hipMalloc((void**)&w.wsc, sizeof(float) * 2 * (size_t)(2 * NB + 1)));
                 TG_HIP(ctx, hipMalloc((void**)&w.stem_h, sizeof(_Float16) * 9 * (size_t)F * 64));
                 TG_HIP(ctx, hipMalloc((void**)&w.head_h, sizeof(_Float16) * 9 * 16 * (size_t)F));
             }
         }
         if (prec >= 1) {
-            TG_HIP(ctx, hipMalloc((void**)&n->act16, act / 2));
-            TG_HIP(ctx, hipMalloc((void**)&n->h16, act / 2));
+            TG_HIP(ctx, hipMalloc((void**)&n->act16, prec == 3 ? act : act / 2));     // split precision: hi + lo per element
+            TG_HIP(ctx, hipMalloc((void**)&n->h16, prec == 3 ? act : act / 2));
             TG_HIP(ctx, hipMalloc((void**)&n->x0h, sizeof(_Float16) * (size_t)rows_cap * P * 64));
         }
         TG_HIP(ctx, hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking));
@@ -1689,7 +1841,7 @@ void tg_net_destroy(tg_ctx* ctx) {
     if (n->pending) (void)hipEventSynchronize(n->loaded);
     void* ptrs[] = {n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->bufQ, n->hca, n->bufAct, n->act16, n->h16, n->x0h, n->tile_ctr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    for (Net::WeightSet& w : n->sets) { void* q[] = {w.blob, w.wstage, w.wh, w.stem_h, w.head_h}; for (void* p : q) if (p) (void)hipFree(p); }
+    for (Net::WeightSet& w : n->sets) { void* q[] = {w.blob, w.wstage, w.wh, w.stem_h, w.head_h, w.wsc}; for (void* p : q) if (p) (void)hipFree(p); }
     if (n->side) (void)hipStreamDestroy(n->side);
     if (n->loaded) (void)hipEventDestroy(n->loaded);
     if (n->swapped) (void)hipEventDestroy(n->swapped);

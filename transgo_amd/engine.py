@@ -103,7 +103,7 @@ class SelfPlayEngine:
                  device=0, evaluator=None, net_precision="f32", record_games=True):
         cfg = _lib.default_config()
         cfg.record_games = 1 if record_games else 0       # per-move records in HBM for tg_sp_harvest (self-play); evaluation matches need none
-        cfg.net_precision = {"f32": 0, "f16": 1, "f16r": 2}[net_precision]
+        cfg.net_precision = {"f32": 0, "f16": 1, "f16r": 2, "f32x3": 3}[net_precision]
         cfg.board_size, cfg.encode_dim, cfg.max_step, cfg.komi = board_size, encode_dim, max_step, komi
         cfg.n_games, cfg.num_simulation, cfg.parallel_readouts, cfg.wu_loss = n_games, num_simulation, parallel_readouts, wu_loss
         cfg.c_puct1, cfg.c_puct2, cfg.arena_slots = c_puct1, c_puct2, arena_slots

@@ -108,3 +108,36 @@ def test_creating_a_context_without_a_gpu_fails_loudly():
     from transgo_amd import _lib
     with pytest.raises(_lib.TransgoError):
         _lib.Context(_lib.default_config())
+
+
+def test_device_code_has_no_out_of_line_calls(tmp_path):
+    """Round 3 (DESIGN.md, 19x19 fault): one out-of-line device function call (k_play<19> -> the ballot-packed encode_bits<19>)
+    corrupted state silently and made the next kernel fault; the same body inlined is fine.  Since then every device helper is
+    __forceinline__ and this test keeps it that way: no s_swappc_b64 (call) in any gfx950 code object of the shipped library."""
+    import shutil
+    import struct
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    data = open(_lib.LIB_PATH, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    pos, n_objs, calls = 0, 0, 0
+    while True:
+        i = data.find(magic, pos)
+        if i < 0:
+            break
+        nb = struct.unpack_from("<Q", data, i + 24)[0]
+        off = i + 32
+        for _ in range(nb):
+            o, sz, tl = struct.unpack_from("<QQQ", data, off); off += 24
+            triple = data[off:off + tl].decode(); off += tl
+            if "gfx950" in triple and sz:
+                f = tmp_path / f"co{n_objs}.o"
+                f.write_bytes(data[i + o:i + o + sz])
+                out = subprocess.run([objdump, "-d", str(f)], stdout=subprocess.PIPE, text=True, check=True).stdout
+                calls += out.count("s_swappc_b64")
+                n_objs += 1
+        pos = i + 24
+    assert n_objs >= 4, "expected one gfx950 code object per .hip source"
+    assert calls == 0, f"{calls} out-of-line device calls in the library"

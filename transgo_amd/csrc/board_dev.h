@@ -146,7 +146,7 @@ template <int S> struct BoardWave : BoardRegs<S> {
 
     // Connected components by min-label propagation + pointer jumping.  with_empty: empty regions are labelled too
     // (needed for Tromp-Taylor scoring only).  Result in L->lab.
-    __device__ void label_groups(bool with_empty) {
+    __device__ __forceinline__ void label_groups(bool with_empty) {
         if constexpr (S == 9) {
             // Barrier-free: every lane grows the group of each of its own points as an 81-bit board in registers (dilate, mask with
             // the stones of that colour -- or the empty points -- until no lane's board changes), then label = lowest point of the
@@ -224,7 +224,7 @@ template <int S> struct BoardWave : BoardRegs<S> {
     }
 
     // Liberties per group label into L->cnt (equivalent observable of Block::liberties, board.h:23).
-    __device__ void count_liberties() {
+    __device__ __forceinline__ void count_liberties() {
         if constexpr (S == 9) {                                          // label_groups(false) left every group's count with its lanes
 #pragma unroll
             for (int k = 0; k < NW; ++k) {
@@ -300,7 +300,7 @@ template <int S> struct BoardWave : BoardRegs<S> {
     // board.cc:731-817 GivenBlockLives for every group of colour `c` at once.  Afterwards bit 0 of aux[label] >> 17
     // ... see alive_at().  Requires analyze().  Uses aux: per point bit 16 = true eye of colour c; low 16 bits per
     // label = number of qualifying eyes.
-    __device__ void mark_alive(int c) {
+    __device__ __forceinline__ void mark_alive(int c) {
 #pragma unroll
         for (int k = 0; k < NW; ++k) L->aux[pt[k]] = 0;
         __syncthreads();
@@ -370,7 +370,7 @@ template <int S> __device__ __forceinline__ bool point_in(const uint64_t* bb, in
 // action: [0,P) point, P or -1 pass, -2 resign.  Returns done; *ok = move accepted.  If `check` is false the caller
 // guarantees legality (tree search only ever plays moves from a legal list) and the test is skipped.
 template <int S>
-__device__ bool state_step(BoardWave<S>& bw, BoardState<S>& st, int action, const RulesCfg& cfg, bool check, bool* ok) {
+__device__ __forceinline__ bool state_step(BoardWave<S>& bw, BoardState<S>& st, int action, const RulesCfg& cfg, bool check, bool* ok) {
     using G = Geo<S>;
     *ok = true;
     if (st.terminated) return true;                                   // go_env.cc:52-55
@@ -445,7 +445,7 @@ template <int S> __device__ __forceinline__ void legal_words(const BoardWave<S>&
 
 // board_feature.cc:213-253 encode9/10/13 as one bit mask per owned point: bit c of m[k] = plane c at point pt[k].
 // Position must be loaded + analysed.  Clobbers L->aux.
-template <int S> __device__ void encode_mask(BoardWave<S>& bw, const BoardState<S>& st, const RulesCfg& cfg, uint32_t* m) {
+template <int S> __device__ __forceinline__ void encode_mask(BoardWave<S>& bw, const BoardState<S>& st, const RulesCfg& cfg, uint32_t* m) {
     using G = Geo<S>;
     const int C = cfg.encode_dim, me = st.next_player, op = 3 - me;
     int pl_h2 = -1, pl_ko = 7, pl_eye = 8, pl_oeye = -1, pl_live = (C == 9) ? -1 : 9, pl_olive = -1;
@@ -502,7 +502,7 @@ template <int S> __device__ void encode_mask(BoardWave<S>& bw, const BoardState<
 }
 
 // -> f32 planes [C][P] at `out` (plane-major, like the reference's Encode, go_env.cc:96-115).
-template <int S> __device__ void encode_planes(BoardWave<S>& bw, const BoardState<S>& st, const RulesCfg& cfg, float* out) {
+template <int S> __device__ __forceinline__ void encode_planes(BoardWave<S>& bw, const BoardState<S>& st, const RulesCfg& cfg, float* out) {
     using G = Geo<S>;
     uint32_t m[G::NW];
     encode_mask(bw, st, cfg, m);
@@ -524,9 +524,11 @@ template <int S> __device__ void encode_planes(BoardWave<S>& bw, const BoardStat
 // that overlap them by shifts.  Other sizes OR the bits into an LDS image with atomics (up to 32 lanes per word: ~4x slower per
 // position, but 19x19 steps are dominated by the tower anyway).
 #ifndef TG_ENCODE_BALLOT19
-#define TG_ENCODE_BALLOT19 0
+#define TG_ENCODE_BALLOT19 1
 #endif
-template <int S> __device__ void encode_bits(BoardWave<S>& bw, const BoardState<S>& st, const RulesCfg& cfg, uint32_t* lds,
+// INL: inline the packing into the calling kernel (what happens by itself at 9x9).  At 19x19 hipcc keeps the function out of
+// line unless told otherwise; see DESIGN.md (round 3, item 6) for why the 19x19 ballot form is only ever used inlined.
+template <int S> __device__ __forceinline__ void encode_bits_body(BoardWave<S>& bw, const BoardState<S>& st, const RulesCfg& cfg, uint32_t* lds,
                                              uint32_t* out) {
     using G = Geo<S>;
     uint32_t m[G::NW];
@@ -570,9 +572,22 @@ template <int S> __device__ void encode_bits(BoardWave<S>& bw, const BoardState<
     }
 }
 
+template <int S> __device__ __noinline__ void encode_bits_call(BoardWave<S>& bw, const BoardState<S>& st, const RulesCfg& cfg, uint32_t* lds,
+                                                              uint32_t* out) { encode_bits_body(bw, st, cfg, lds, out); }
+// TG_ENCODE_INLINE_MASK (diagnostic builds): bit 0 k_reset, bit 1 k_collect, bit 2 k_play take the inlined form; default: the
+// compiler decides for the LDS form, and the ballot form is always inlined
+#ifndef TG_ENCODE_INLINE_MASK
+#define TG_ENCODE_INLINE_MASK -1
+#endif
+template <int S, int SITE> __device__ __forceinline__ void encode_bits(BoardWave<S>& bw, const BoardState<S>& st, const RulesCfg& cfg,
+                                                                       uint32_t* lds, uint32_t* out) {
+    if constexpr (S == 9 || TG_ENCODE_INLINE_MASK == -1 || ((TG_ENCODE_INLINE_MASK >> SITE) & 1)) encode_bits_body(bw, st, cfg, lds, out);
+    else encode_bits_call(bw, st, cfg, lds, out);
+}
+
 // board.cc:822-958 getTTScore.  Loads colours itself.  Returns raw Tromp-Taylor area difference (0 on an empty board,
 // board.cc:932-935); owner[k] (optional, per lane slot): 1 black, 2 white, 3 dame.
-template <int S> __device__ float tromp_taylor(BoardWave<S>& bw, const BoardState<S>& st, uint8_t* owner) {
+template <int S> __device__ __forceinline__ float tromp_taylor(BoardWave<S>& bw, const BoardState<S>& st, uint8_t* owner) {
     using G = Geo<S>;
     bw.load_colors(st.bb[0], st.bb[1]);
     bw.label_groups(true);

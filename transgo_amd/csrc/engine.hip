@@ -54,7 +54,7 @@ template <int S> __device__ __forceinline__ BlockHdr<S>* hdr_of(NodeRec* arena, 
 // Allocate and write the block of a node whose position `st` is loaded + analysed in `bw`: header + one fresh child
 // record per legal action (Node_V.expand with prior 0.0, self_play.py:70-77, :634-636).  Returns the block slot or -1.
 template <int S>
-__device__ int make_block(BoardWave<S>& bw, const BoardState<S>& st, NodeRec* arena, int& free_slot, int cap, bool children) {
+__device__ __forceinline__ int make_block(BoardWave<S>& bw, const BoardState<S>& st, NodeRec* arena, int& free_slot, int cap, bool children) {
     using G = Geo<S>;
     constexpr int HS = TreeGeo<S>::HS;
     uint64_t lw[G::NW];
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void k_reset(EngineDev d, const uint8_t* mask, 
     bw.analyze();
     int free_slot = 1;
     int blk = make_block(bw, st, arena, free_slot, d.sc.arena_slots, !over);
-    if (!over) encode_bits(bw, st, d.rules, bits_s, d.obs_bits + (size_t)g * d.sc.R * d.obs_words);      // the game's slot 0
+    if (!over) encode_bits<S, 0>(bw, st, d.rules, bits_s, d.obs_bits + (size_t)g * d.sc.R * d.obs_words);      // the game's slot 0
     if (bw.lane == 0) {
         NodeRec r;                                                    // Node_V(0), self_play.py:596 / :691
         r.prior = 0.0; r.w = 0.f; r.var = 0.f; r.n = 0; r.pending = 0; r.block = blk; r.action = 0xFFFF; r.flags = 0; r.term = 0;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
             const int blk = make_block(bw, st, arena, free_slot, sc.arena_slots, true);
             TG_ST(4);
             row = nslot++;                                             // the game's own next slot: no allocation, no atomic
-            encode_bits(bw, st, d.rules, bits_s, d.obs_bits + ((size_t)g * sc.R + row) * d.obs_words);   // self_play.py:798
+            encode_bits<S, 1>(bw, st, d.rules, bits_s, d.obs_bits + ((size_t)g * sc.R + row) * d.obs_words);   // self_play.py:798
             TG_ST(5);
             if (lane == 0) {
                 arena[node].block = blk;
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions
         for (int i = lane; i < nchild; i += 64) { NodeRec r = old[rblk + HS + i]; cnt[r.action] = r.n; }
         bw.load_colors(st.bb[0], st.bb[1]);
         bw.analyze();
-        encode_bits(bw, st, d.rules, bits_s, d.hist_obs + e * d.obs_words);
+        encode_bits<S, 2>(bw, st, d.rules, bits_s, d.hist_obs + e * d.obs_words);
         if (lane == 0) d.hist_pl[e] = st.next_player;
     }
     bool ok;
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions
         child.block = blk; child.term = 0; child.flags &= (uint8_t)~F_PSEUDO;
         if (lane == 0) nw[0] = child;
         if (!done) {
-            encode_bits(bw, st, d.rules, bits_s, d.obs_bits + (size_t)g * sc.R * d.obs_words);     // the game's slot 0
+            encode_bits<S, 2>(bw, st, d.rules, bits_s, d.obs_bits + (size_t)g * sc.R * d.obs_words);  // the game's slot 0
             if (lane == 0) { c->need_eval = 1; c->root_row = 0; d.game_nslot[g] = 1; }
         }
     }
@@ -757,6 +757,20 @@ int tg_engine_create(tg_ctx* ctx) {
     e->h_nchild.resize(G);
     e->arena_bytes = arena_bytes;
     TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (g_trace_launch) {                                             // where every engine buffer lives: a fault address can be placed
+        const EngineDev& v = e->dev;
+        auto pr = [](const char* n, const void* p, size_t b) { fprintf(stderr, "[tg buf] %-10s %p .. %p (%zu B)\n", n, p, (const char*)p + b, b); };
+        pr("arena", v.arena, arena_bytes); pr("ctl", v.ctl, sizeof(GameCtl) * G); pr("rng", v.rng, sizeof(tg_mt19937) * G);
+        pr("path_nodes", v.path_nodes, sizeof(int32_t) * (size_t)G * R * sc.maxd); pr("path_len", v.path_len, sizeof(int32_t) * (size_t)G * R);
+        pr("path_row", v.path_row, sizeof(int32_t) * (size_t)G * R); pr("obs_bits", v.obs_bits, sizeof(uint32_t) * (size_t)e->rows_cap * v.obs_words);
+        pr("row_slot", v.row_slot, sizeof(int32_t) * (size_t)e->rows_cap); pr("game_nslot", v.game_nslot, sizeof(int32_t) * (size_t)G);
+        pr("game_off", v.game_off, sizeof(int32_t) * (size_t)G); pr("game_act", v.game_act, (size_t)G);
+        pr("policy", v.policy, sizeof(float) * (size_t)e->rows_cap * A); pr("value", v.value, sizeof(float) * (size_t)e->rows_cap);
+        pr("counters", v.counters, sizeof(int32_t) * CNT_N);
+        if (v.hist_obs) { const size_t n = (size_t)G * v.hist_T; pr("hist_obs", v.hist_obs, sizeof(uint32_t) * n * v.obs_words);
+                          pr("hist_cnt", v.hist_cnt, sizeof(int32_t) * n * A); pr("hist_pl", v.hist_pl, n); }
+        fflush(stderr);
+    }
     return TG_OK;
 }
 

@@ -89,7 +89,7 @@ struct WaveRng {
     int pos;
     uint32_t* scratch;      // 1248 words of LDS
     unsigned long long draws;
-    __device__ void twist() {
+    __device__ __forceinline__ void twist() {
         const int lane = lane_id();
         uint32_t* o = scratch; uint32_t* nw = scratch + 624;
         __syncthreads();
@@ -109,7 +109,7 @@ struct WaveRng {
         __syncthreads();
         pos = 0;
     }
-    __device__ uint32_t next32() {
+    __device__ __forceinline__ uint32_t next32() {
         if (pos >= 624) twist();
         uint32_t y = key[pos++];
         ++draws;
@@ -117,7 +117,7 @@ struct WaveRng {
         return y;
     }
     // RandomState.choice(list of k): masked rejection on 32-bit words, no draw when k == 1 (self_play.py:709-713)
-    __device__ int choice_index(int k) {
+    __device__ __forceinline__ int choice_index(int k) {
         if (k <= 1) return 0;
         uint32_t rng = (uint32_t)(k - 1), mask = rng;
         mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;

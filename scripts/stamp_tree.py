@@ -20,7 +20,7 @@ for _ in range(moves):                     # into the middle game first
     sp.advance(num_simulation=16)
 fn(None, 1)
 sp.advance()
-out = (ctypes.c_ulonglong * 16)()
+out = (ctypes.c_ulonglong * 24)()
 fn(out, 0)
 names = ["selection", "parent state + step", "terminal scoring + backup", "child load_colors + analyze", "make_block (legality + child records)",
          "encode_bits (features)", "pending + bookkeeping", "-"]
@@ -29,3 +29,8 @@ print(f"game-waves {nw}, mean cycles per game-wave {tot / max(1, nw):.0f}")
 for i, n in enumerate(names[:7]):
     print(f"  {n:45s} {100.0 * out[i] / tot:5.1f} %   {out[i] / max(1, nw):8.0f} cycles")
 print(f"  {'unaccounted (setup, exit)':45s} {100.0 * (tot - sum(out[:7])) / tot:5.1f} %")
+sub = ["encode: suicide mask (shared with legality when make_block ran first)", "encode: liberty classes + eyes", "encode: mark_alive + alive_at",
+       "encode: plane masks", "encode: ballot packing + store", "make_block: legal_words", "make_block: header + child records"]
+print("sub-phases inside the board code:")
+for i, n in enumerate(sub):
+    print(f"  {n:75s} {100.0 * out[16 + i] / tot:5.1f} %   {out[16 + i] / max(1, nw):8.0f} cycles")

@@ -78,6 +78,16 @@ template <> struct BoardRegs<9> {
     uint16_t lib_r[2];      //                 and their liberty counts
 };
 
+// Diagnostic builds (-DTG_TREE_STAMP): s_memtime sub-phase stamps inside the board code, accumulated in the BoardWave and flushed
+// by k_collect together with its own phases (scripts/stamp_tree.py)
+#ifdef TG_TREE_STAMP
+#define TG_BW_ST_BEGIN(bw) (bw).st2_t = __builtin_amdgcn_s_memtime()
+#define TG_BW_ST(bw, i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (bw).st2[i] += n_ - (bw).st2_t; (bw).st2_t = n_; } while (0)
+#else
+#define TG_BW_ST_BEGIN(bw)
+#define TG_BW_ST(bw, i)
+#endif
+
 // Everything a lane knows about its NW points.
 template <int S> struct BoardWave : BoardRegs<S> {
     using G = Geo<S>;
@@ -87,10 +97,20 @@ template <int S> struct BoardWave : BoardRegs<S> {
     int pt[NW];         // point index (may be >= P: invalid)
     uint8_t nbv[NW];    // bit d set: neighbour d on board (d: 0 L, 1 U, 2 R, 3 D = go_comm.h:44-45); bits 4-7: diagonals
     uint8_t col[NW];    // colour of own point (kWall if invalid)
+#ifdef TG_TREE_STAMP
+    unsigned long long st2[8], st2_t;
+#endif
+    uint8_t su_valid;   // 0, or 1 + the player su_bits was computed for (reset by analyze())
+    uint8_t su_bits;    // bit k: isSuicideMove(player) at own slot k (only meaningful for empty points)
 
     __device__ __forceinline__ void init(WaveLds<S>* lds) {
         L = lds;
         lane = lane_id();
+        su_valid = 0; su_bits = 0;
+#ifdef TG_TREE_STAMP
+        for (int i = 0; i < 8; ++i) st2[i] = 0;
+        st2_t = 0;
+#endif
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
             int p = k * 64 + lane;
@@ -225,10 +245,13 @@ template <int S> struct BoardWave : BoardRegs<S> {
 
     // Liberties per group label into L->cnt (equivalent observable of Block::liberties, board.h:23).
     __device__ __forceinline__ void count_liberties() {
-        if constexpr (S == 9) {                                          // label_groups(false) left every group's count with its lanes
+        su_valid = 0;
+        if constexpr (S == 9) {
+            // label_groups(false) left every group's count with ALL of its stones' lanes, so at 9x9 the table is indexed by POINT:
+            // cnt[p] = liberties of the group at p -- one LDS read per lookup (lib_at) instead of label then count
 #pragma unroll
             for (int k = 0; k < NW; ++k) {
-                L->cnt[pt[k]] = (this->lab_r[k] == (uint16_t)pt[k]) ? (uint32_t)this->lib_r[k] : 0u;
+                L->cnt[pt[k]] = (uint32_t)this->lib_r[k];
                 L->aux[pt[k]] = 0;
             }
             __syncthreads();
@@ -259,7 +282,7 @@ template <int S> struct BoardWave : BoardRegs<S> {
     }
     __device__ __forceinline__ void analyze() { label_groups(false); count_liberties(); }
 
-    __device__ __forceinline__ int lib_at(int q) const { return (int)L->cnt[L->lab[q]]; }
+    __device__ __forceinline__ int lib_at(int q) const { return S == 9 ? (int)L->cnt[q] : (int)L->cnt[L->lab[q]]; }
 
     // board.cc:130-158 isSuicideMove for `player` at own slot k (point must be empty).
     __device__ __forceinline__ bool suicide(int k, int player) const {
@@ -276,11 +299,27 @@ template <int S> struct BoardWave : BoardRegs<S> {
         }
         return s;
     }
+    // isSuicideMove for `player` at every own empty point, computed once per analysed position: legality (make_block) and the
+    // ko/suicide feature plane (encode_mask) ask for the same player's answers (board.cc:467-489, board_feature.cc:69-89)
+    __device__ __forceinline__ void ensure_suicide(int player) {
+        if (su_valid == 1 + player) return;                              // wave-uniform
+        uint8_t b = 0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+            if (pt[k] < G::P && col[k] == kEmpty && suicide(k, player)) b |= (uint8_t)(1u << k);
+        su_bits = b; su_valid = (uint8_t)(1 + player);
+    }
+    __device__ __forceinline__ bool suicide_cached(int k) const { return (su_bits >> k) & 1; }
     // board.cc:432-464 TryPlay for board points, on an analysed position.
     template <class St> __device__ __forceinline__ bool legal(int k, const St& st, int player) const {
         if (col[k] != kEmpty) return false;
         if (st.ko_location == pt[k] && st.ko_age == 0 && st.ko_color == player) return false;   // board.cc:198-200
         return !suicide(k, player);
+    }
+    template <class St> __device__ __forceinline__ bool legal_cached(int k, const St& st, int player) const {   // after ensure_suicide(player)
+        if (col[k] != kEmpty) return false;
+        if (st.ko_location == pt[k] && st.ko_age == 0 && st.ko_color == player) return false;
+        return !suicide_cached(k);
     }
     // board.cc:665-714 isTrueEye
     __device__ __forceinline__ bool true_eye(int k, int player) const {
@@ -350,7 +389,7 @@ template <int S> struct BoardWave : BoardRegs<S> {
     }
     __device__ __forceinline__ bool alive_at(int k) const {
         uint32_t g = L->lab[pt[k]];
-        return (int)L->cnt[g] >= 2 && (L->aux[g] & 0xFFFFu) >= 2;
+        return lib_at(pt[k]) >= 2 && (L->aux[g] & 0xFFFFu) >= 2;
     }
 };
 
@@ -408,7 +447,7 @@ __device__ __forceinline__ bool state_step(BoardWave<S>& bw, BoardState<S>& st, 
         if (c == kEmpty) { ++self_lib; continue; }
         if (c == player) { own_nb = true; continue; }
         uint32_t g = bw.L->lab[q];
-        if (bw.L->cnt[g] == 1) {
+        if (bw.lib_at(q) == 1) {
             cap[d] = g;                                               // captured: its only liberty is `action`
             // single-stone group <=> no same-colour neighbour (board.cc:181-187)
             int qx = q % S, qy = q / S;
@@ -438,9 +477,10 @@ __device__ __forceinline__ bool state_step(BoardWave<S>& bw, BoardState<S>& st, 
 }
 
 // Legal points of the side to move as bitboard words (board.cc:467-489).  Position must be loaded + analysed.
-template <int S> __device__ __forceinline__ void legal_words(const BoardWave<S>& bw, const BoardState<S>& st, uint64_t* out) {
+template <int S> __device__ __forceinline__ void legal_words(BoardWave<S>& bw, const BoardState<S>& st, uint64_t* out) {
+    bw.ensure_suicide(st.next_player);
 #pragma unroll
-    for (int k = 0; k < Geo<S>::NW; ++k) out[k] = ballot64(bw.pt[k] < Geo<S>::P && bw.legal(k, st, st.next_player));
+    for (int k = 0; k < Geo<S>::NW; ++k) out[k] = ballot64(bw.pt[k] < Geo<S>::P && bw.legal_cached(k, st, st.next_player));
 }
 
 // board_feature.cc:213-253 encode9/10/13 as one bit mask per owned point: bit c of m[k] = plane c at point pt[k].
@@ -456,6 +496,9 @@ template <int S> __device__ __forceinline__ void encode_mask(BoardWave<S>& bw, c
     // liberty classes, ko/suicide and eyes first: mark_alive() clobbers nothing they need, but keep the order explicit
     int cls[G::NW];          // 0/1/2 liberty class of a stone, -1 otherwise
     bool kosu[G::NW], eye_me[G::NW], eye_op[G::NW];
+    TG_BW_ST_BEGIN(bw);
+    bw.ensure_suicide(me);
+    TG_BW_ST(bw, 0);
 #pragma unroll
     for (int k = 0; k < G::NW; ++k) {
         cls[k] = -1; kosu[k] = false; eye_me[k] = false; eye_op[k] = false;
@@ -466,11 +509,12 @@ template <int S> __device__ __forceinline__ void encode_mask(BoardWave<S>& bw, c
             cls[k] = l == 1 ? 0 : l == 2 ? 1 : l >= 3 ? 2 : -1;
         } else {
             bool ko = (st.ko_age == 0 && st.ko_location == bw.pt[k]);   // board.cc:205-213 (ko_color ignored)
-            kosu[k] = ko || bw.suicide(k, me);                          // board.cc:520-533, board_feature.cc:69-89
+            kosu[k] = ko || bw.suicide_cached(k);                       // board.cc:520-533, board_feature.cc:69-89
             eye_me[k] = bw.true_eye(k, me);                             // board_feature.cc:142-161
             if (pl_oeye >= 0) eye_op[k] = bw.true_eye(k, op);
         }
     }
+    TG_BW_ST(bw, 1);
     if (pl_live >= 0) {                                                 // board_feature.cc:164-182
         bw.mark_alive(me);
 #pragma unroll
@@ -481,6 +525,7 @@ template <int S> __device__ __forceinline__ void encode_mask(BoardWave<S>& bw, c
 #pragma unroll
         for (int k = 0; k < G::NW; ++k) live_op[k] = (bw.col[k] == op) && bw.alive_at(k);
     }
+    TG_BW_ST(bw, 2);
 #pragma unroll
     for (int k = 0; k < G::NW; ++k) {
         const int p = bw.pt[k];
@@ -534,6 +579,7 @@ template <int S> __device__ __forceinline__ void encode_bits_body(BoardWave<S>& 
     uint32_t m[G::NW];
     encode_mask(bw, st, cfg, m);
     const int C = cfg.encode_dim, W = (C * G::P + 31) / 32;
+    TG_BW_ST(bw, 3);
     if constexpr (S == 9 || TG_ENCODE_BALLOT19) {
         constexpr int WPL = ((13 * G::P + 31) / 32 + 63) / 64;      // output words per lane (1 at 9x9, 3 at 19x19)
         uint32_t word[WPL];
@@ -556,6 +602,7 @@ template <int S> __device__ __forceinline__ void encode_bits_body(BoardWave<S>& 
         }
 #pragma unroll
         for (int q = 0; q < WPL; ++q) { const int w = q * 64 + bw.lane; if (w < W) out[w] = word[q]; }
+        TG_BW_ST(bw, 4);
     } else {
         for (int i = bw.lane; i < W; i += 64) lds[i] = 0;
         __syncthreads();

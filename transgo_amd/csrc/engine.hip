@@ -21,11 +21,12 @@ namespace {
 
 // In-kernel phase stamps of k_collect (diagnostic builds only: -DTG_TREE_STAMP; scripts/stamp_tree.py prints them).
 #ifdef TG_TREE_STAMP
-__device__ unsigned long long g_stamp[16];
+__device__ unsigned long long g_stamp[16], g_stamp2[8];
 #define TG_ST_DECL unsigned long long st_t = __builtin_amdgcn_s_memtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long st_t0 = st_t
 #define TG_ST(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[i] += n_ - st_t; st_t = n_; } while (0)
 #define TG_ST_FLUSH() do { if (lane == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_stamp[i_], st_acc[i_]); \
-                            atomicAdd(&g_stamp[8], __builtin_amdgcn_s_memtime() - st_t0); atomicAdd(&g_stamp[9], 1ull); } } while (0)
+                            atomicAdd(&g_stamp[8], __builtin_amdgcn_s_memtime() - st_t0); atomicAdd(&g_stamp[9], 1ull); \
+                            for (int i_ = 0; i_ < 7; ++i_) atomicAdd(&g_stamp2[i_], bw.st2[i_]); } } while (0)
 #else
 #define TG_ST_DECL
 #define TG_ST(i)
@@ -59,8 +60,10 @@ __device__ __forceinline__ int make_block(BoardWave<S>& bw, const BoardState<S>&
     constexpr int HS = TreeGeo<S>::HS;
     uint64_t lw[G::NW];
     int npts = 0;
+    TG_BW_ST_BEGIN(bw);
     if (children) {
         legal_words(bw, st, lw);
+        TG_BW_ST(bw, 5);
 #pragma unroll
         for (int k = 0; k < G::NW; ++k) npts += __popcll(lw[k]);
     } else {
@@ -90,6 +93,7 @@ __device__ __forceinline__ int make_block(BoardWave<S>& bw, const BoardState<S>&
         base += __popcll(lw[k]);
     }
     if (children && npts == 0 && lane == 0) { r.action = (uint16_t)G::P; arena[blk + HS] = r; }
+    TG_BW_ST(bw, 6);
     return blk;
 }
 
@@ -1224,7 +1228,9 @@ int tg_prof_read_tree(tg_ctx* ctx, double* collect_ms, double* absorb_ms, int64_
 // diagnostic builds: summed s_memtime cycles per k_collect phase [0..7], whole-kernel cycles [8], game-waves [9]; reset = 1 clears
 int tg_debug_tree_stamps(unsigned long long* out, int reset) {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 16) != hipSuccess) return TG_ERR_HIP;
-    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)) != hipSuccess) return TG_ERR_HIP; }
+    if (out && hipMemcpyFromSymbol(out + 16, HIP_SYMBOL(g_stamp2), sizeof(unsigned long long) * 8) != hipSuccess) return TG_ERR_HIP;   // out: 24 words
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)) != hipSuccess) return TG_ERR_HIP;
+                 if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp2), z, sizeof(unsigned long long) * 8) != hipSuccess) return TG_ERR_HIP; }
     return TG_OK;
 }
 #endif

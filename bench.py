@@ -181,6 +181,9 @@ def parse_args(argv=None):
     ap.add_argument("--stagger", type=int, default=-1,
                     help="spread the boards over this many ply offsets before the warm-up (default: max_step at 9x9, 0 = all "
                          "boards start together, at 19x19)")
+    ap.add_argument("--arena-slots", type=int, default=0,
+                    help="32-byte tree slots per game and half arena (default: (3*sims + 256) * (header + actions)); the line reports "
+                         "the high-water mark and any truncated tree blocks, so a 19x19 run can be sized for more boards per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=0.0,
                     help="window of each CPU-baseline leg (default: 60 s at N = 1 as BASELINE.md 4 says, 30 s at N > 1)")
@@ -336,7 +339,7 @@ def main(argv=None):
     cfg = Config(num_simulation=a.sims, num_features=a.filters, num_blocks=a.blocks, board_size=S,
                  max_step=a.max_step or (120 if S == 9 else 450), inference_dtype=a.dtype, network=a.network)
     gpu = local if backend == "nccl" else 0
-    sp = BatchedSelfPlay(cfg, a.games, device=gpu, rank=rank, world=world)
+    sp = BatchedSelfPlay(cfg, a.games, device=gpu, rank=rank, world=world, arena_slots=a.arena_slots)
     if a.network == "transgo":
         sp.set_weights(model.random_transgo_weights(S, 10, a.filters, seed=1234))
     else:
@@ -465,6 +468,7 @@ def main(argv=None):
             "extra": {"leaves_per_s": round(evals_all / dt, 1), "mean_depth": round(depth_all / max(1.0, sims_all), 3),
                       "net_tflops_end_to_end": round(evals_all * fpl / dt / 1e12, 2) if fpl else None,
                       "tree_errors": st1["errors"], "arena_high_water_slots": st1["max_slots"],
+                      "arena_slots_per_half": int(eng.ctx.cfg.arena_slots) or (3 * a.sims + 256) * ((2 if S == 9 else 4) + S * S + 1),
                       "truncated_tree_blocks": st1["truncated_blocks"],
                       "step_phases_ms": dict({k: round(v / a.steps * 1e3, 2) for k, v in sp.phase_s.items()},
                                              begin_move_inside_search=round(eng.begin_move_s / a.steps * 1e3, 2)),

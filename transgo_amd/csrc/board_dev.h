@@ -322,14 +322,19 @@ template <int S> struct BoardWave : BoardRegs<S> {
         return !suicide_cached(k);
     }
     // board.cc:665-714 isTrueEye
+    // The own point as a value the optimiser cannot see through: without it hipcc hoists one LDS address per (slot, neighbour offset,
+    // table) out of the read-out loop of k_collect -- dozens of registers live across the whole kernel at a 128-register budget,
+    // spilled to scratch and reloaded ~65 times per read-out, each reload waiting behind the block's HBM stores (one in-order counter)
+    __device__ __forceinline__ int own_point(int k) const { int p = pt[k]; asm volatile("" : "+v"(p)); return p; }
     __device__ __forceinline__ bool true_eye(int k, int player) const {
         if (col[k] != kEmpty) return false;
         bool eye = true;
         int nwall = 0, nopp = 0;
+        const int pk = own_point(k);
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            if (nbv[k] >> d & 1) { if (L->col[pt[k] + nb_off(d)] != player) eye = false; }
-            if (nbv[k] >> (4 + d) & 1) { if (L->col[pt[k] + dg_off(d)] == (3 - player)) ++nopp; }
+            if (nbv[k] >> d & 1) { if (L->col[pk + nb_off(d)] != player) eye = false; }
+            if (nbv[k] >> (4 + d) & 1) { if (L->col[pk + dg_off(d)] == (3 - player)) ++nopp; }
             else ++nwall;
         }
         bool fake = (nwall > 0 && nopp >= 1) || (nwall == 0 && nopp >= 2);
@@ -354,11 +359,12 @@ template <int S> struct BoardWave : BoardRegs<S> {
         for (int k = 0; k < NW; ++k) {
             if (!eye[k]) continue;
             uint32_t gl[4];
+            const int pk = own_point(k);
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 gl[d] = kNone;
                 if (!(nbv[k] >> d & 1)) continue;
-                uint32_t g = L->lab[pt[k] + nb_off(d)];
+                uint32_t g = L->lab[pk + nb_off(d)];
                 bool dup = false;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (e < d && gl[e] == g) dup = true;
@@ -369,7 +375,7 @@ template <int S> struct BoardWave : BoardRegs<S> {
 #pragma unroll
                 for (int dd = 0; dd < 4; ++dd) {
                     if (!(nbv[k] >> (4 + dd) & 1)) { ++nb; continue; }
-                    int q = pt[k] + dg_off(dd);
+                    int q = pk + dg_off(dd);
                     int cq = L->col[q];
                     if (cq == c) { ++nt; continue; }
                     if (cq != kEmpty || !(L->aux[q] >> 16 & 1)) continue;

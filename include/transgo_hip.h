@@ -212,8 +212,8 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch, const float* blob, size_t n_
  * blocks until it is. */
 int tg_net_load_async(tg_ctx* ctx, const char* arch, const float* blob, size_t n_floats);
 /* The same with the blob in THIS GPU's memory (e.g. the buffer an RCCL broadcast filled): copied device -> device, no host
- * bounce.  Its contents must be complete when the call is made; the buffer is free again when the call returns.  Needs a network
- * of this architecture already loaded. */
+ * bounce.  Its contents must be complete when the call is made; the buffer is free again when the call returns.  Without a
+ * network of this architecture loaded yet it falls back to the synchronous load (one copy through the host). */
 int tg_net_load_async_dev(tg_ctx* ctx, const char* arch, const float* d_blob /*device*/, size_t n_floats);
 int tg_net_load_poll(tg_ctx* ctx, int wait, int* pending);
 /* main_prediction (model.py:17-20) on host buffers: obs f32[n][C][S][S] -> policy f32[n][A] (softmax), value f32[n]

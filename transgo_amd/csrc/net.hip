@@ -1863,9 +1863,13 @@ int tg_net_load_async(tg_ctx* ctx, const char* arch_c, const float* blob, size_t
 int tg_net_load_async_dev(tg_ctx* ctx, const char* arch_c, const float* d_blob, size_t n_floats) {
     if (!ctx || !d_blob || !arch_c) return TG_ERR_ARG;
     Net* n = ctx->eng ? ctx->eng->net : nullptr;
-    if (!n || n->arch != arch_c || n->blob_floats != n_floats || n->prec != ctx->cfg.net_precision)
-        TG_FAIL(ctx, TG_ERR_STATE, "tg_net_load_async_dev: needs a network of this architecture already loaded (tg_net_load_arch first)");
     TG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    if (!n || n->arch != arch_c || n->blob_floats != n_floats || n->prec != ctx->cfg.net_precision) {
+        // nothing to refresh yet (first weights of this context, or another architecture): the synchronous load, through the host
+        std::vector<float> host(n_floats);
+        TG_HIP(ctx, hipMemcpy(host.data(), d_blob, sizeof(float) * n_floats, hipMemcpyDeviceToHost));
+        return tg_net_load_arch(ctx, arch_c, host.data(), n_floats, 0);
+    }
     { int rc = adopt_pending(ctx, n, /*wait=*/true); if (rc) return rc; }
     TG_HIP(ctx, hipStreamWaitEvent(n->side, n->swapped, 0));
     { int rc = fill_weight_set(ctx, n, n->active ^ 1, d_blob, n->side, /*blob_on_device=*/true); if (rc) return rc; }

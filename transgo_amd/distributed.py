@@ -16,7 +16,12 @@ from . import records
 
 
 def _active():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """True when there is a process group to talk to.  A group of ONE rank counts only with TRANSGO_DIST_SINGLE_RANK=1: that is how
+    the RCCL code paths (device-resident control words, size exchange, weight broadcast, device -> device weight load) are
+    exercised on a one-GPU box, where a second RCCL rank cannot exist (tests/test_gpu_rccl.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("TRANSGO_DIST_SINGLE_RANK", "0") == "1"
 
 
 def init_process_group(backend, rank, world, device_index=None, timeout_s=1800.0, init_method=None):

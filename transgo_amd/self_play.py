@@ -310,7 +310,8 @@ class SelfPlay:
     @staticmethod
     def _dist():
         import torch.distributed as dist
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        from .distributed import _active
+        multi = _active()
         return dist, multi, (dist.get_rank() if multi else 0), (dist.get_world_size() if multi else 1)
 
     def _fetch_blob(self, shared_storage_worker):
@@ -383,8 +384,9 @@ class SelfPlay:
                 wk.arch = _model.transgo_arch()
             n = _model._lib.load().tg_net_blob_floats_arch(wk.S, wk.config.encode_state_channels, wk.filters, wk.arch.code.encode())
         got = broadcast_weights(blob, src=0, device=dev, n_floats=n)
-        # rank 0 already holds the host blob; the receiving ranks load what the broadcast left in their GPU memory, device -> device
-        wk.set_weights_blob(blob if rank == 0 else got, background=True)
+        # over RCCL every rank (the sender included) loads what the broadcast left in its GPU memory, device -> device
+        # (tg_net_load_async_dev: no host bounce); over gloo the NumPy blob goes through the pinned staging buffer
+        wk.set_weights_blob(got if hasattr(got, "is_cuda") else (blob if rank == 0 else got), background=True)
 
     def _refresh_weights(self, shared_storage_worker):
         """self_play.py:913 alone (no throttle): see _move_prologue."""

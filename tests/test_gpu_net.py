@@ -241,29 +241,3 @@ def test_f32_conv_both_tile_shapes():
     for got, n in ((big, 1700), (small, 1500)):
         assert np.abs(got[0] - p[:n]).max() < TOL and np.abs(got[1] - v[:n]).max() < TOL and np.abs(got[2] - o[:n]).max() < TOL
     assert np.array_equal(big[0][:1500], small[0]) and np.array_equal(big[1][:1500], small[1])
-
-
-@pytest.mark.parametrize("S,F,NB,n", [(9, 128, 3, 1700), (9, 128, 2, 1500), (19, 256, 2, 3), (9, 256, 1, 40)])
-def test_slim_stem_is_bit_identical_to_the_two_copy_form(monkeypatch, S, F, NB, n):
-    """Round 3: when a residual block follows the stem, the stem writes the residual stream once (slice-major, not activated) and
-    block 0 activates it in registers (k_conv3x3_sg PROB) and reads its residual slice-major (RSM) -- half the stem's HBM writes.
-    Per element the arithmetic is unchanged, so the outputs must equal the two-copy form (TG_STEM_FULL=1) BIT FOR BIT, on both
-    tile shapes of F = 128 (1700 positions: 192-row tiles, 1500: 128-row tiles), at F = 256 and at 19x19; and stay within 1e-3 of
-    fp32 torch."""
-    import torch
-    from oracle.net import seeded_tower
-    from transgo_amd.model import HipNetwork
-    torch.set_num_threads(8)
-    net = seeded_tower(S, 10, F, NB, seed=77 + NB)
-    x = _positions(S, n, 14)
-    h = HipNetwork(S, 10, F, NB, rows_cap=max(8, n))
-    h.set_weights(net.get_weights())
-    monkeypatch.setenv("TG_STEM_FULL", "1")
-    full = h.main_prediction(x)
-    monkeypatch.setenv("TG_STEM_FULL", "0")
-    slim = h.main_prediction(x)
-    assert all(np.array_equal(a, b) for a, b in zip(full, slim))
-    k = min(n, 64)
-    with torch.no_grad():
-        p, v, o = [t.numpy() for t in net.main_prediction(torch.from_numpy(x[:k]))]
-    assert np.abs(slim[0][:k] - p).max() < TOL and np.abs(slim[1][:k] - v).max() < TOL and np.abs(slim[2][:k] - o).max() < TOL

@@ -167,7 +167,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[CT][NPT], const int (
 
 // EPI 0: out = relu(acc + bias)      EPI 1: out = acc + bias + res      EPI 2: out = acc + bias
 // NTAP 9: 3x3 convolution with zero padding; NTAP 1: 1x1 convolution (the q/k/v projections of Self_Attention, model.py:294-296)
-template <int S, int CIN, int COUT, bool PRO, int EPI, int NTAP = 9, int NPT = 2, bool SM2 = false, bool SM1 = false>
+template <int S, int CIN, int COUT, bool PRO, int EPI, int NTAP = 9, int NPT = 2, bool SM2 = false>
 // NPT = 3 only pays with two waves per SIMD (<= 256 registers, a handful of spills): measured 132 vs 118 TFLOP/s at one
 __global__ __launch_bounds__(256, (NPT > 2 ? 2 : 1)) void k_conv3x3(const float* __restrict__ in, float* __restrict__ out,
                                                  const float* __restrict__ res, const float* __restrict__ Wt,
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256, (NPT > 2 ? 2 : 1)) void k_conv3x3(const float*
     int mrow[NPT];
 #pragma unroll
     for (int t = 0; t < NPT; ++t) mrow[t] = m0 + (wave * NPT + t) * 16 + j;
-    conv_epilogue<COUT, CT, NPT, EPI, SM1, SM2>(acc, mrow, M, 0, kq, out, res, out2, par);
+    conv_epilogue<COUT, CT, NPT, EPI, false, SM2>(acc, mrow, M, 0, kq, out, res, out2, par);
 }
 
 // LDS pointer type of the LDS-DMA builtins; counted wait on the in-order vector-memory counter (loads, stores and LDS-DMA share it)
@@ -364,19 +364,12 @@ __device__ __forceinline__ int swz64(int row) { return ((row >> 2) & 1) << 1; }
 // shape when the batch fills whole rounds of the 768 resident slots, e.g. exactly 16384 leaves = 9.0 rounds) and for 2 (128 rows,
 // four per CU, 1024 slots): in steady state a wave evaluates ~15.7 k leaves = 8.63 rounds of the first shape, whose partial last
 // round costs almost a full one; the host picks per launch whichever shape wastes less of its last round (+2 % in steady state).
-// PROB / RSM serve the FIRST residual block of a tower, whose input is the stem's output: the stem then writes the residual stream
-// once, slice-major and not activated (half the bytes of "row-major stream + activated slice-major copy"; the stem is bound by its
-// HBM writes), conv1 of block 0 applies relu(bn1(.)) to its B fragments in registers (PROB: two LDS reads of the slice's scale /
-// shift per stage, 8 vector instructions per fragment beside 24-32 MFMAs; masked taps and rows past the batch are zeroed AFTER the
-// activation, as the padding is post-activation) and conv2 of block 0 starts its accumulators from the slice-major stream (RSM).
-// The arithmetic per element is the stem epilogue's (v * s + t, unfused), so results are bit-identical to the two-copy form.
-template <int S, int F, int EPI, int NPT_ = (F == 128 ? 3 : 2), bool PROB = false, bool RSM = false>
+template <int S, int F, int EPI, int NPT_ = (F == 128 ? 3 : 2)>
 __global__ __launch_bounds__(256, (F == 128 ? (NPT_ == 3 ? 3 : 4) : 2)) void k_conv3x3_sg(const float* __restrict__ in, float* __restrict__ out,
                                                                        const float* __restrict__ res, const float* __restrict__ Ws,
                                                                        const float* __restrict__ bias, float* __restrict__ out2,
                                                                        const float* __restrict__ s2, const float* __restrict__ t2, int M,
-                                                                       int* __restrict__ ctr, const float* __restrict__ ps = nullptr,
-                                                                       const float* __restrict__ pt = nullptr) {
+                                                                       int* __restrict__ ctr) {
     constexpr int P = S * S, CT = F / 16, CC = 16;
     constexpr int NPT = NPT_, TM = 64 * NPT;
     constexpr int WPW = CT / 4;
@@ -384,14 +377,12 @@ __global__ __launch_bounds__(256, (F == 128 ? (NPT_ == 3 ? 3 : 4) : 2)) void k_c
     static_assert((F == 128 || F == 256) && NST % NGS == 0, "tile geometry");
     __shared__ __attribute__((aligned(16))) float ws[D][F * CC];
     __shared__ __attribute__((aligned(16))) float par[3 * F];
-    __shared__ __attribute__((aligned(16))) float pro[PROB ? 2 * F : 4];     // PROB: input-channel scale | shift
     __shared__ int next_tile;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, kq = lane >> 4;
     int m0 = blockIdx.x * TM;
     for (int i = tid; i < F; i += 256) { par[i] = bias[i]; par[F + i] = out2 ? s2[i] : 0.f; par[2 * F + i] = out2 ? t2[i] : 0.f; }
-    if (PROB) for (int i = tid; i < F; i += 256) { pro[i] = ps[i]; pro[F + i] = pt[i]; }
 
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, M * F * 4, 0x00020000);
     const int prow = lane >> 2, pchunk = (lane & 3) ^ swz64(lane >> 2);
@@ -442,22 +433,10 @@ __global__ __launch_bounds__(256, (F == 128 ? (NPT_ == 3 ? 3 : 4) : 2)) void k_c
             for (int ct = 0; ct < CT; ++ct) {                            // EPI 1: start from the residual (no loads behind the epilogue's stores)
                 acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 // always issued (rows past the batch re-read the last row; they are never stored): the wait at the loop head counts them
-                if (EPI == 1) acc[ct][t] = *reinterpret_cast<const f32x4*>(res + (RSM ? f32_sm_index(m < M ? m : M - 1, ct * 16 + kq * 4, M)
-                                                                                             : (size_t)(m < M ? m : M - 1) * F + ct * 16 + kq * 4));
+                if (EPI == 1) acc[ct][t] = *reinterpret_cast<const f32x4*>(res + (size_t)(m < M ? m : M - 1) * F + ct * 16 + kq * 4);
             }
         }
-        load_b(PROB ? b_next : b_cur, 0);                               // PROB: activated into b_cur behind the tile's first barrier
-    };
-    // PROB: b_cur = relu(b_next * s + t) for the 4 input channels this lane holds of stage g's slice; masked taps / rows stay zero
-    auto activate_b = [&](int g) {
-        const int sl = g / 9, tap = g % 9;
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(pro + sl * CC + kq * 4), sh = *reinterpret_cast<const f32x4*>(pro + F + sl * CC + kq * 4);
-#pragma unroll
-        for (int t = 0; t < NPT; ++t) {
-            const bool on = (vmask[t] >> tap) & 1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { float u = b_next[t][e] * sc[e] + sh[e]; u = u > 0.f ? u : 0.f; b_cur[t][e] = on ? u : 0.f; }
-        }
+        load_b(b_cur, 0);
     };
 #pragma unroll
     for (int g = 0; g < D; ++g) dma_w(g);
@@ -470,7 +449,6 @@ __global__ __launch_bounds__(256, (F == 128 ? (NPT_ == 3 ? 3 : 4) : 2)) void k_c
         TG_VMCNT((EPI == 1 ? CT * NPT : 0) + NPT);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         TG_BARRIER();
-        if (PROB) activate_b(0);
 
 #pragma unroll 1
         for (int pp = 0; pp < NGRP; ++pp) {
@@ -493,11 +471,8 @@ __global__ __launch_bounds__(256, (F == 128 ? (NPT_ == 3 ? 3 : 4) : 2)) void k_c
                     a_cur = a_next;
                 }
                 TG_VMCNT(0);                                             // B fragments of stage g+1 (and any weight pieces): a stage old
-                if (PROB) { if (g + 1 < NST) activate_b(g + 1); }
-                else {
 #pragma unroll
-                    for (int t = 0; t < NPT; ++t) b_cur[t] = b_next[t];
-                }
+                for (int t = 0; t < NPT; ++t) b_cur[t] = b_next[t];
             }
             TG_BARRIER();                                                // group pp+1 has landed for everybody; the slots of group pp are free
             if (NGS * (pp + 2) < NST) {
@@ -1444,18 +1419,9 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
             const bool act0 = nl && n->layers[0].kind == 0;
             if (act0) { s0 = n->blocks[n->layers[0].ridx].s1; t0 = n->blocks[n->layers[0].ridx].t1; }
             if (n->NB) (void)hipMemsetAsync(n->tile_ctr, 0, sizeof(int) * 2 * n->NB, st);     // dynamic tile counters of the conv launches
-            // slim stem (the default when a residual block follows): the stream once, slice-major, not activated; block 0 activates
-            // it in registers (k_conv3x3_sg PROB / RSM).  TG_STEM_FULL=1: the two-copy form (row-major stream + activated copy).
-            const char* sf = getenv("TG_STEM_FULL");                         // read per forward: a test compares the two forms in one process
-            const bool stem_full = sf && atoi(sf) != 0;
-            const bool slim = act0 && !stem_full;
-            if (slim)
-                hipLaunchKernelGGL((k_conv3x3<S, 16, F, false, 0, 9, 2, false, true>), dim3(grid), dim3(256), 0, st, (const float*)n->x0, x,
-                                   (const float*)nullptr, n->stem.w, n->stem.b, (const float*)nullptr, (const float*)nullptr, M);
-            else
-                hipLaunchKernelGGL((k_conv3x3<S, 16, F, false, 0, 9, 2, true>), dim3(grid), dim3(256), 0, st, (const float*)n->x0, x,
-                                   (const float*)nullptr, n->stem.w, n->stem.b, (const float*)nullptr, (const float*)nullptr, M,
-                                   act0 ? n->bufAct : (float*)nullptr, s0, t0);
+            hipLaunchKernelGGL((k_conv3x3<S, 16, F, false, 0, 9, 2, true>), dim3(grid), dim3(256), 0, st, (const float*)n->x0, x,
+                               (const float*)nullptr, n->stem.w, n->stem.b, (const float*)nullptr, (const float*)nullptr, M,
+                               act0 ? n->bufAct : (float*)nullptr, s0, t0);
             constexpr int WQ = F / 4 + F / 4 + F;
             auto attention_fast = [&](const AttW& a, const float* xin, float* xout, const float* ps, const float* pt, float* o2,
                                       const float* sn, const float* tn) {
@@ -1491,30 +1457,15 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                 const int grid_sd = ntile_sd < slots_sd ? ntile_sd : slots_sd;
                 int* const ctr1 = n->tile_ctr + 2 * L.ridx; int* const ctr2 = ctr1 + 1;              // zeroed at the top of the forward
                 float* const actn = act ? n->bufAct : (float*)nullptr;
-                const bool first_slim = slim && i == 0;                  // block 0 behind the slim stem: x is slice-major and not activated
                 { ProfScope ps(n, st, conv_flops);
-                  if (first_slim) {
-                      if (small_tiles)
-                          hipLaunchKernelGGL((k_conv3x3_sg<S, F, 0, 2, true, false>), dim3(grid_sd), dim3(256), 0, st, (const float*)x, n->bufH,
-                                             (const float*)nullptr, b.g1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, ctr1, b.s1, b.t1);
-                      else
-                          hipLaunchKernelGGL((k_conv3x3_sg<S, F, 0, (F == 128 ? 3 : 2), true, false>), dim3(grid_sd), dim3(256), 0, st, (const float*)x, n->bufH,
-                                             (const float*)nullptr, b.g1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, ctr1, b.s1, b.t1);
-                  } else if (small_tiles)
+                  if (small_tiles)
                       hipLaunchKernelGGL((k_conv3x3_sg<S, F, 0, 2>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufAct, n->bufH,
                                          (const float*)nullptr, b.g1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, ctr1);
                   else
                       hipLaunchKernelGGL((k_conv3x3_sg<S, F, 0>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufAct, n->bufH,
                                          (const float*)nullptr, b.g1, b.c1.b, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, ctr1); }
                 { ProfScope ps(n, st, conv_flops);
-                  if (first_slim) {
-                      if (small_tiles)
-                          hipLaunchKernelGGL((k_conv3x3_sg<S, F, 1, 2, false, true>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufH, y,
-                                             (const float*)x, b.g2, b.c2.b, actn, sn, tn, M, ctr2);
-                      else
-                          hipLaunchKernelGGL((k_conv3x3_sg<S, F, 1, (F == 128 ? 3 : 2), false, true>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufH, y,
-                                             (const float*)x, b.g2, b.c2.b, actn, sn, tn, M, ctr2);
-                  } else if (small_tiles)
+                  if (small_tiles)
                       hipLaunchKernelGGL((k_conv3x3_sg<S, F, 1, 2>), dim3(grid_sd), dim3(256), 0, st, (const float*)n->bufH, y,
                                          (const float*)x, b.g2, b.c2.b, actn, sn, tn, M, ctr2);
                   else

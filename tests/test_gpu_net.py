@@ -241,3 +241,30 @@ def test_f32_conv_both_tile_shapes():
     for got, n in ((big, 1700), (small, 1500)):
         assert np.abs(got[0] - p[:n]).max() < TOL and np.abs(got[1] - v[:n]).max() < TOL and np.abs(got[2] - o[:n]).max() < TOL
     assert np.array_equal(big[0][:1500], small[0]) and np.array_equal(big[1][:1500], small[1])
+
+
+@pytest.mark.parametrize("S,F,NB,n", [(9, 128, 2, 1), (9, 128, 2, 213), (9, 32, 2, 70), (9, 256, 1, 45), (19, 128, 1, 5), (19, 256, 1, 3)])
+def test_head_gemm_equals_the_implicit_gemm_head(monkeypatch, S, F, NB, n):
+    """Round 3: the 16-wide head conv (6 real couts) runs as GEMM + col2im (k_head_gemm: every input row times all 9 taps' weights,
+    then the shifted sum with the board mask) instead of an implicit GEMM that fills 6 of 16 MFMA columns.  Same products, another
+    summation order: outputs within 2e-6 of the kernel it replaced (TG_HEAD_GEMM=0) on batches that end inside a tile, on one
+    board, at every filter count built and at 19x19, and within 1e-3 of fp32 torch."""
+    import torch
+    from oracle.net import seeded_tower
+    from transgo_amd.model import HipNetwork
+    torch.set_num_threads(8)
+    net = seeded_tower(S, 10, F, NB, seed=500 + F)
+    x = _positions(S, n, 21)
+    h = HipNetwork(S, 10, F, NB, rows_cap=max(8, n))
+    h.set_weights(net.get_weights())
+    monkeypatch.setenv("TG_HEAD_GEMM", "0")
+    old = h.main_prediction(x)
+    monkeypatch.setenv("TG_HEAD_GEMM", "1")
+    new = h.main_prediction(x)
+    e = [float(np.abs(a - b).max()) for a, b in zip(old, new)]
+    print(f"head GEMM {NB}x{F}@{S}x{S} n={n}: max abs difference to the implicit-GEMM head policy {e[0]:.2e} value {e[1]:.2e} own {e[2]:.2e}")
+    assert max(e) < 2e-6
+    k = min(n, 32)
+    with torch.no_grad():
+        p, v, o = [t.numpy() for t in net.main_prediction(torch.from_numpy(x[:k]))]
+    assert np.abs(new[0][:k] - p).max() < TOL and np.abs(new[1][:k] - v).max() < TOL and np.abs(new[2][:k] - o).max() < TOL

@@ -43,6 +43,7 @@ struct Net {
     int* tile_ctr = nullptr;                       // [2*NB] tile counters of the persistent conv launches (zeroed per forward)
     int prec = 0;                                  // cfg.net_precision: 0 = f32, 1 = fp16 storage + f32 accumulate (k_conv3x3_h2), 2 = 1 + fp16 residual stream,
                                                    // 3 = split precision ("f32x3"): every operand as fp16 hi + lo, all four products on the fp16 MFMA, f32 accumulate
+    const float* head_g = nullptr; const float* head_ag = nullptr;   // [64][F] head conv weights for k_head_gemm (tap*6 + cout rows)
     float* wsc = nullptr;                          // prec 3: [2*NB + 1] power-of-two factor 2^-s each conv's weights were scaled by before splitting (stem last)
     _Float16* stem_h = nullptr; _Float16* head_h = nullptr; _Float16* x0h = nullptr;   // fp16 path: stem [2*9][F][32] (16 planes padded to 64), head [F/32*9][16][32], input [rows][P][64]
     _Float16* wh = nullptr; _Float16* act16 = nullptr; _Float16* h16 = nullptr;   // fp16 path: weights [2*NB][F/32*9][F][32], activations [rows][P][F]
@@ -61,7 +62,7 @@ struct Net {
     // running -- and the next forward that finds it complete rebinds.  `swapped` orders a later refill of the retired set behind
     // every kernel that may still read it.
     struct WeightSet { float* blob = nullptr; float* wstage = nullptr; _Float16* wh = nullptr; _Float16* stem_h = nullptr; _Float16* head_h = nullptr;
-                       float* wsc = nullptr; };
+                       float* wsc = nullptr; float* head_g = nullptr; float* head_ag = nullptr; };   // head_g / head_ag: k_head_gemm copies of head / head_a
     WeightSet sets[2]; int active = 0; bool pending = false;
     hipStream_t side = nullptr; hipEvent_t loaded = nullptr, swapped = nullptr; float* pinned = nullptr;
     // profiling of the dominant kernel (3x3 conv F->F) with HIP events on the launch stream
@@ -1009,6 +1010,114 @@ __global__ __launch_bounds__(256, 2) void k_head_h(const _Float16* __restrict__ 
     }
 }
 
+// ---- head conv (F -> the 6 real couts of the 16-wide head tensor: value/ownership conv 2 + policy conv 4, model.py:65-76) --------
+// As an implicit GEMM a 6-cout conv fills 6 of the 16 columns of an MFMA tile: 0.44 ms per 16 k leaves at 9x9 / F = 128, a third of
+// it useful.  Here it is "GEMM, then col2im": every INPUT row m is multiplied once by all 9 taps' weights,
+//     D[m][tap*6 + co] = sum_c act(x[m][c]) * W[tap][co][c]          (54 useful of 64 columns = 4 MFMA N-tiles),
+// and an output is out[p][co] = relu(bias[co] + sum_tap D[p + off(tap)][tap*6 + co]) over the taps that stay on the board.  MFMAs
+// per output row: 4 N-tiles x F/4 steps x (1 + halo share) instead of 9 taps x F/4 -- 10.7 vs 18 per row at 9x9 / F = 128.
+// No LDS operand staging and no barrier in the GEMM phase: a wave keeps its B fragments (the whole 64 x F weight matrix at F <= 128,
+// two N-tiles per pass above) in registers and streams A fragments (16 rows x 64 B of the row-major stream) straight from L2, the
+// next row tile's in flight while this one computes; D goes to LDS (row stride 68 floats: the four 16-lane groups of a store hit
+// disjoint banks) for the col2im pass.  Workgroups walk the tile list (at F <= 128 the weights are fetched once per wave).  PRO: the
+// input is the residual stream and relu(bn_end(.)) is applied to the A fragments in registers (rows outside the batch stay zero).
+template <int S, int F, bool PRO>
+__global__ __launch_bounds__(256, 2) void k_head_gemm(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ W2,
+                                                      const float* __restrict__ bias, const float* __restrict__ ps,
+                                                      const float* __restrict__ pt, int M, int ntiles) {
+    constexpr int P = S * S, HALO = S + 1, NTW = S == 9 ? 3 : 4, NROW = 64 * NTW, TM = NROW - 2 * HALO, LDW = 68, NK = F / 16;
+    constexpr int NTP = F <= 128 ? 4 : 2, NPASS = 4 / NTP;               // N-tiles whose B fragments a wave holds at once
+    constexpr bool DBUF = F <= 128;                                     // room to keep the next row tile's A fragments in flight
+    __shared__ __attribute__((aligned(16))) float dl[NROW * LDW];
+    __shared__ __attribute__((aligned(16))) float pro[PRO ? 2 * F : 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, kq = lane >> 4;
+    if (PRO) for (int i = tid; i < F; i += 256) { pro[i] = ps[i]; pro[F + i] = pt[i]; }
+    __syncthreads();
+    auto load_a = [&](f32x4* a, int row) {                              // A fragments of one row tile: x[row][k16*16 + kq*4 .. +3]
+        const bool ok = row >= 0 && row < M;
+        const float* src = in + (size_t)(ok ? row : 0) * F + kq * 4;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) a[k] = ok ? *reinterpret_cast<const f32x4*>(src + k * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    f32x4 bw[NTP][NK];                                                  // B fragments: W2[n = nt*16 + j][k16*16 + kq*4 .. +3]
+    auto load_b = [&](int pass) {
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt)
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+                bw[nt][k] = *reinterpret_cast<const f32x4*>(W2 + (size_t)((pass * NTP + nt) * 16 + j) * F + k * 16 + kq * 4);
+    };
+    if (NPASS == 1) load_b(0);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * TM, r0 = m0 - HALO;
+#pragma unroll 1
+        for (int pass = 0; pass < NPASS; ++pass) {
+            if (NPASS > 1) load_b(pass);
+            f32x4 a[DBUF ? 2 : 1][NK];
+            load_a(a[0], r0 + (wave * NTW) * 16 + j);
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                const int rt = wave * NTW + i, row = r0 + rt * 16 + j;
+                f32x4* cur = a[DBUF ? (i & 1) : 0];
+                if (DBUF && i + 1 < NTW) load_a(a[(i + 1) & 1], row + 16);
+                const bool ok = row >= 0 && row < M;
+                f32x4 acc[NTP];
+#pragma unroll
+                for (int nt = 0; nt < NTP; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                int po = kq * 4;                                        // opaque per row tile: the scale / shift reads stay inside the loop
+                asm volatile("" : "+v"(po));                            // (hoisted they are 2 * F / 4 registers per lane: spills at F = 256)
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    f32x4 v = cur[k];
+                    if (PRO) {
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(pro + k * 16 + po), sh = *reinterpret_cast<const f32x4*>(pro + F + k * 16 + po);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { float u = v[e] * sc[e] + sh[e]; u = u > 0.f ? u : 0.f; v[e] = ok ? u : 0.f; }
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NTP; ++nt)
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[s4], bw[nt][k][s4], acc[nt], 0, 0, 0);
+                }
+                // D tile: row = A's M index = kq*4 + r, column = B's N index = j
+#pragma unroll
+                for (int nt = 0; nt < NTP; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dl[(rt * 16 + kq * 4 + r) * LDW + (pass * NTP + nt) * 16 + j] = acc[nt][r];
+                if (!DBUF && i + 1 < NTW) load_a(a[0], row + 16);
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < TM * 8; idx += 256) {
+            const int o = idx >> 3, co = idx & 7, m = m0 + o;
+            if (m >= M) continue;
+            float v = 0.f;
+            if (co < 6) {
+                const int p = m % P, x = p % S, y = p / S;
+                v = bias[co];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                    if (y + dy >= 0 && y + dy < S && x + dx >= 0 && x + dx < S) v += dl[(o + HALO + dy * S + dx) * LDW + tap * 6 + co];
+                }
+                v = v > 0.f ? v : 0.f;
+            }
+            out[(size_t)m * 16 + co] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// the head conv's weights for k_head_gemm: dst[n = tap*6 + co][c] = w[tap][co][c] for co < 6 (w is [9][16][F]), rows 54..63 zero
+__global__ __launch_bounds__(256) void k_restage_head(const float* __restrict__ w, float* __restrict__ dst, int F) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 64 * F; i += gridDim.x * 256) {
+        const int n = i / F, c = i % F;
+        dst[i] = n < 54 ? w[((size_t)(n / 6) * 16 + n % 6) * F + c] : 0.f;
+    }
+}
+
 // Self_Attention core (model.py:301-315) for one board per workgroup, after the fused q/k/v 1x1 projection:
 //   energy[i][j] = q_i . k_j ; attention = softmax_j(energy) ; out[:, j] = sum_i v[:, i] * attention[i][j]   (note: summed over
 //   the softmaxed ROW index i, exactly as torch.bmm(proj_value, attention) does)
@@ -1309,6 +1418,20 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
     constexpr int NPT = F <= 128 ? 3 : 2;
     const int grid_f = (M + 64 * NPT - 1) / (64 * NPT);
     const double conv_flops = 2.0 * 9.0 * (double)F * (double)F * (double)M;
+    // head conv F -> 16 (6 real couts): GEMM + col2im (k_head_gemm); TG_HEAD_GEMM=0 selects the implicit-GEMM kernel it replaced
+    auto head_conv = [&](const float* in, float* outp, const float* Wg, const ConvW& cw, const float* ps, const float* pt) {
+        const char* hg = getenv("TG_HEAD_GEMM");
+        if (hg && atoi(hg) == 0) {
+            if (ps) hipLaunchKernelGGL((k_conv3x3<S, F, 16, true, 0>), dim3(grid), dim3(256), 0, st, in, outp, (const float*)nullptr, cw.w, cw.b, ps, pt, M);
+            else hipLaunchKernelGGL((k_conv3x3<S, F, 16, false, 0>), dim3(grid), dim3(256), 0, st, in, outp, (const float*)nullptr, cw.w, cw.b,
+                                    (const float*)nullptr, (const float*)nullptr, M);
+            return;
+        }
+        constexpr int TMH = 64 * (S == 9 ? 3 : 4) - 2 * (S + 1);
+        const int nt = (M + TMH - 1) / TMH, g = nt < 512 ? nt : 512;      // two workgroups per CU walk the tile list
+        if (ps) hipLaunchKernelGGL((k_head_gemm<S, F, true>), dim3(g), dim3(256), 0, st, in, outp, Wg, cw.b, ps, pt, M, nt);
+        else hipLaunchKernelGGL((k_head_gemm<S, F, false>), dim3(g), dim3(256), 0, st, in, outp, Wg, cw.b, (const float*)nullptr, (const float*)nullptr, M, nt);
+    };
     int g0 = (int)(((size_t)M * 16 + 255) / 256); if (g0 > 65535) g0 = 65535;
     if (n->prec == 0) {
         if (n->in_bits) hipLaunchKernelGGL((k_bits_to_rows<S>), dim3(g0), dim3(256), 0, st, n->in_bits, n->in_slot, n->x0, rows, n->C, n->in_words);
@@ -1347,8 +1470,7 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                 float* t = x; x = y; y = t;
             }
             // the head conv is 16 couts wide (one MFMA tile): the f32 kernel reads the f32 residual stream and activates while staging
-            hipLaunchKernelGGL((k_conv3x3<S, F, 16, true, 0>), dim3(grid), dim3(256), 0, st, (const float*)x, n->hc,
-                               (const float*)nullptr, n->head.w, n->head.b, n->s_end, n->t_end, M);
+            head_conv(x, n->hc, n->head_g, n->head, n->s_end, n->t_end);
             hipLaunchKernelGGL((k_heads<S>), dim3((rows + HeadRows<S>::N - 1) / HeadRows<S>::N), dim3(256), 0, st, (const float*)n->hc, (const float*)n->hc, n->w_vo, n->b_vo,
                                n->w_v, n->b_v, n->w_o, n->b_o, n->w_a, n->b_a, policy, value, own, rows);
             TG_HIP(ctx, hipGetLastError());
@@ -1474,13 +1596,11 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                 float* t = x; x = y; y = t;
             }
             // bufAct / bufH are slice-major; the head convs read the row-major residual stream and activate it while staging
-            hipLaunchKernelGGL((k_conv3x3<S, F, 16, true, 0>), dim3(grid), dim3(256), 0, st, (const float*)x, n->hc,
-                               (const float*)nullptr, n->head.w, n->head.b, n->s_end, n->t_end, M);
+            head_conv(x, n->hc, n->head_g, n->head, n->s_end, n->t_end);
             const float* hca = n->hc;
             if (n->pol_att) {                              // attention in the policy head (model.py:72,106-107) on relu(bn_end(x))
                 attention_fast(n->patt, x, y, n->s_end, n->t_end, (float*)nullptr, (const float*)nullptr, (const float*)nullptr);
-                hipLaunchKernelGGL((k_conv3x3<S, F, 16, false, 0>), dim3(grid), dim3(256), 0, st, (const float*)y, n->hca,
-                                   (const float*)nullptr, n->head_a.w, n->head_a.b, (const float*)nullptr, (const float*)nullptr, M);
+                head_conv(y, n->hca, n->head_ag, n->head_a, nullptr, nullptr);
                 hca = n->hca;
             }
             hipLaunchKernelGGL((k_heads<S>), dim3((rows + HeadRows<S>::N - 1) / HeadRows<S>::N), dim3(256), 0, st, (const float*)n->hc, hca, n->w_vo, n->b_vo,
@@ -1525,13 +1645,11 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
     }
     // heads: value/ownership conv reads relu(bn_end(x)) (model.py:94,97); the policy conv reads the same tensor, or its
     // Self_Attention when the architecture has attention_act (model.py:72,106-107)
-    hipLaunchKernelGGL((k_conv3x3<S, F, 16, true, 0>), dim3(grid), dim3(256), 0, st, (const float*)x, n->hc,
-                       (const float*)nullptr, n->head.w, n->head.b, n->s_end, n->t_end, M);
+    head_conv(x, n->hc, n->head_g, n->head, n->s_end, n->t_end);
     const float* hca = n->hc;
     if (n->pol_att) {
         if (attention(n->patt, x, y, n->s_end, n->t_end)) TG_FAIL(ctx, TG_ERR_ARG, "attention policy head: not enough LDS at this board size");
-        hipLaunchKernelGGL((k_conv3x3<S, F, 16, false, 0>), dim3(grid), dim3(256), 0, st, (const float*)y, n->hca,
-                           (const float*)nullptr, n->head_a.w, n->head_a.b, (const float*)nullptr, (const float*)nullptr, M);
+        head_conv(y, n->hca, n->head_ag, n->head_a, nullptr, nullptr);
         hca = n->hca;
     }
     hipLaunchKernelGGL((k_heads<S>), dim3((rows + HeadRows<S>::N - 1) / HeadRows<S>::N), dim3(256), 0, st, (const float*)n->hc, hca, n->w_vo, n->b_vo, n->w_v, n->b_v,
@@ -1587,7 +1705,7 @@ size_t expected_floats(int S, int C, int F, const std::string& arch) {
 void bind_weights(Net* n, int k) {
     const int F = n->F; const size_t P = n->P, A = n->A, Wq = (size_t)F / 4 * 2 + F;
     const Net::WeightSet& w = n->sets[k];
-    n->blob = w.blob; n->wstage = w.wstage; n->wh = w.wh; n->stem_h = w.stem_h; n->head_h = w.head_h; n->wsc = w.wsc;
+    n->blob = w.blob; n->wstage = w.wstage; n->wh = w.wh; n->stem_h = w.stem_h; n->head_h = w.head_h; n->wsc = w.wsc; n->head_g = w.head_g; n->head_ag = w.head_ag;
     std::string trunk; bool pol = false;
     parse_arch(n->arch, &trunk, &pol);
     const float* p = w.blob;
@@ -1633,6 +1751,8 @@ int fill_weight_set(tg_ctx* ctx, Net* n, int k, const float* blob, hipStream_t s
     }
     Net view = *n;                                        // pointer fields of set k without disturbing the live binding
     bind_weights(&view, k);
+    hipLaunchKernelGGL(k_restage_head, dim3(64), dim3(256), 0, st, view.head.w, n->sets[k].head_g, F);
+    if (n->pol_att) hipLaunchKernelGGL(k_restage_head, dim3(64), dim3(256), 0, st, view.head_a.w, n->sets[k].head_ag, F);
     if (n->prec == 3) {
         // split copies (hi | lo of w * 2^s per conv), made on the device from the blob just uploaded; the scale words double as the
         // scratch of the abs-max reduction (bit patterns), overwritten with 2^-s by the restaging kernel that follows in order
@@ -1749,6 +1869,8 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
         if (n->dma) TG_HIP(ctx, hipMalloc((void**)&n->tile_ctr, sizeof(int) * (size_t)(NB > 0 ? 2 * NB : 1)));
         for (Net::WeightSet& w : n->sets) {
             TG_HIP(ctx, hipMalloc((void**)&w.blob, sizeof(float) * n_floats));
+            TG_HIP(ctx, hipMalloc((void**)&w.head_g, sizeof(float) * 64 * (size_t)F));
+            if (pol) TG_HIP(ctx, hipMalloc((void**)&w.head_ag, sizeof(float) * 64 * (size_t)F));
             if (n->dma) TG_HIP(ctx, hipMalloc((void**)&w.wstage, sizeof(float) * wcopy));
             if (prec >= 1) {
                 TG_HIP(ctx, hipMalloc((void**)&w.wh, sizeof(_Float16) * wcopy * (prec == 3 ? 2 : 1)));
@@ -1845,7 +1967,7 @@ void tg_net_destroy(tg_ctx* ctx) {
     if (n->pending) (void)hipEventSynchronize(n->loaded);
     void* ptrs[] = {n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->bufQ, n->hca, n->bufAct, n->act16, n->h16, n->x0h, n->tile_ctr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    for (Net::WeightSet& w : n->sets) { void* q[] = {w.blob, w.wstage, w.wh, w.stem_h, w.head_h, w.wsc}; for (void* p : q) if (p) (void)hipFree(p); }
+    for (Net::WeightSet& w : n->sets) { void* q[] = {w.blob, w.wstage, w.wh, w.stem_h, w.head_h, w.wsc, w.head_g, w.head_ag}; for (void* p : q) if (p) (void)hipFree(p); }
     if (n->side) (void)hipStreamDestroy(n->side);
     if (n->loaded) (void)hipEventDestroy(n->loaded);
     if (n->swapped) (void)hipEventDestroy(n->swapped);

@@ -410,8 +410,8 @@ def main(argv=None):
         # HBM bytes per launch of the dominant kernel come from PMC passes (separate rocprofv3 runs, committed under profiles/);
         # they only describe the configuration they were collected on
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json" if a.dtype == "f32" else "r1_pmc_traffic_f16.json")
-        if a.dtype in ("f32", "f16") and os.path.exists(tfile) and (S, a.filters, a.games, a.network) == (9, 128, 4096, "tower"):
+        tfile = os.path.join(ROOT, "profiles", {"f32": "r3_pmc_traffic.json", "f32x3": "r3_pmc_f32x3.json"}.get(a.dtype, "r1_pmc_traffic_f16.json"))
+        if a.dtype in ("f32", "f16", "f32x3") and os.path.exists(tfile) and (S, a.filters, a.games, a.network) == (9, 128, 4096, "tower"):
             with open(tfile) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch_mean")
         value = sims_all / dt

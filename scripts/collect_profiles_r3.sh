@@ -30,11 +30,4 @@ python3 bench.py --gpus 1 --steps 20 --warmup 5 2> $OUT/line_default.err | grep 
 say default line done
 TRANSGO_DIST_BACKEND=gloo python3 bench.py --gpus 2 --games 1024 --steps 3 --warmup 1 2> $OUT/line_n2.err | grep "^{" > $OUT/line_n2_gloo.json
 say n2 done
-# long 19x19 run of the shipped build (ballot-packed planes, no out-of-line device calls): 1024 boards x 120 moves x 200 sims
-python3 bench.py --board 19 --sims 200 --filters 128 --blocks 2 --games 1024 --steps 120 --warmup 2 --no-cpu-baseline --dtype f16r 2> $OUT/soak19.err | grep "^{" > $OUT/soak19_line.json
-say soak19 done
-C5="--board 19 --sims 1600 --filters 256 --blocks 40 --games 1024 --steps 2 --warmup 1 --no-cpu-baseline"
-python3 bench.py $C5 --dtype f16r 2> $OUT/c5_f16r.err | grep "^{" > $OUT/line_c5_f16r.json
-say c5 done
-python3 -m pytest tests/test_gpu_split_precision.py -q -s 2>&1 | grep -E "f32x3|passed|failed" > $OUT/x3_parity.txt
 du -sh $OUT; ls -la $OUT

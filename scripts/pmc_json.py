@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/collect_profiles.sh -> profiles/r2_pmc_traffic.json.
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/collect_profiles_r3.sh -> profiles/rN_pmc_traffic.json.
 usage: pmc_json.py [gpurun_out/prof_r2] [out.json]"""
 import collections, csv, glob, json, statistics, sys
 
@@ -20,7 +20,7 @@ def load(d, counter):
 
 
 fe, wr = load(ROOT + "/fetch", "FETCH_SIZE"), load(ROOT + "/write", "WRITE_SIZE")
-out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, scripts/collect_profiles.sh) on `python3 bench.py "
+out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, scripts/collect_profiles_r3.sh) on `python3 bench.py "
                  "--steps 1 --warmup 1 --no-cpu-baseline`; medians over the launches of the last (timed) step -- for the conv kernel over its "
                  "full-batch launches (grid within 5 % of the largest)",
        "correction": "FETCH_SIZE doubled (gfx950 tallies 128-B requests as 64 B: MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact; counter unit KB",
@@ -41,7 +41,7 @@ for k in sorted(set(fe) | set(wr)):
     e = {"launches_summarised": len(f), "grid_size_median": grid, "FETCH_SIZE_KB_raw_median": round(fk, 1), "WRITE_SIZE_KB_median": round(wk, 1),
          "hbm_bytes_per_launch": round((2 * fk + wk) * 1024.0, 1), "duration_us_median": round(statistics.median(x[2] for x in f) / 1e3, 2)}
     if conv:
-        npt, epi = int(k.split(",")[3].strip(" >")), int(k.split(",")[2])
+        npt, epi = int(k.split(",")[3].strip(" >")), int(k.split(",")[2])                     # k_conv3x3_sg<S, F, EPI, NPT>
         rows = grid / 256 * 64 * npt
         alg = (8 * F if epi == 0 else 16 * F) * rows
         e.update(tile_rows=64 * npt, rows_per_launch_approx=int(rows), algorithmic_bytes_per_launch=int(alg),

@@ -904,14 +904,25 @@ __global__ __launch_bounds__(256) void k_obs_to_rows_h(const float* __restrict__
 template <int S>
 __global__ __launch_bounds__(256) void k_bits_to_rows_h(const uint32_t* __restrict__ bits, const int32_t* __restrict__ row_slot,
                                                         _Float16* __restrict__ x0, int rows, int C, int W) {
+    // one thread = one 16-B chunk (8 channels of one row) of the chunk-major tensor; consecutive threads walk a chunk plane, so the
+    // stores are contiguous (round 2 wrote 2-B elements scattered over the planes: 97 us per 16 k leaves, now ~25)
     constexpr int P = S * S;
-    const size_t total = (size_t)rows * P * 64;
+    const size_t M = (size_t)rows * P, total = M * 8;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i & 63);
-        const size_t m = i >> 6;
-        const int p = (int)(m % P), k = c * P + p;
-        const size_t r = m / P;
-        x0[h16_index((int)m, c, rows * P)] = c < C ? (_Float16)(float)((bits[(size_t)row_slot[r] * W + (k >> 5)] >> (k & 31)) & 1u) : (_Float16)0.f;
+        const int cp = (int)(i / M);
+        const size_t m = i - (size_t)cp * M;
+        h8 o = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if (cp * 8 < C) {
+            const size_t r = m / P;
+            const int p = (int)(m - r * P);
+            const uint32_t* base = bits + (size_t)row_slot[r] * W;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = cp * 8 + e, k = c * P + p;
+                if (c < C) o[e] = (_Float16)(float)((base[k >> 5] >> (k & 31)) & 1u);
+            }
+        }
+        *reinterpret_cast<h8*>(x0 + (i << 3)) = o;                       // h16_index(m, cp * 8, M) = (cp * M + m) * 8
     }
 }
 
@@ -1448,7 +1459,7 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
             constexpr int COS = F / 128;
             const int nblk_h2 = COS == 1 ? grid_h : (grid_h + 7) / 8 * 8 * COS;
             const size_t nb = n->blocks.size();
-            int g0h = (int)(((size_t)M * 64 + 255) / 256); if (g0h > 65535) g0h = 65535;
+            int g0h = (int)(((size_t)M * 8 + 255) / 256); if (g0h > 65535) g0h = 65535;
             if (n->in_bits) hipLaunchKernelGGL((k_bits_to_rows_h<S>), dim3(g0h), dim3(256), 0, st, n->in_bits, n->in_slot, n->x0h, rows, n->C, n->in_words);
             else hipLaunchKernelGGL((k_obs_to_rows_h<S>), dim3(g0h), dim3(256), 0, st, obs, n->x0h, rows, n->C);
             const float* wsc = n->wsc;
@@ -1491,7 +1502,7 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
             const size_t nb = n->blocks.size();
             // stem on the fp16 matrix cores too (input planes are 0/1, exact in fp16; 16 planes padded to 64 channels = 18 stages):
             // writes the f32 residual stream x and the first conv input relu(bn_next(x)) as fp16
-            int g0h = (int)(((size_t)M * 64 + 255) / 256); if (g0h > 65535) g0h = 65535;
+            int g0h = (int)(((size_t)M * 8 + 255) / 256); if (g0h > 65535) g0h = 65535;
             if (n->in_bits) hipLaunchKernelGGL((k_bits_to_rows_h<S>), dim3(g0h), dim3(256), 0, st, n->in_bits, n->in_slot, n->x0h, rows, n->C, n->in_words);
             else hipLaunchKernelGGL((k_obs_to_rows_h<S>), dim3(g0h), dim3(256), 0, st, obs, n->x0h, rows, n->C);
             if (r16)

@@ -345,6 +345,9 @@ __device__ __forceinline__ void tg_dma_buffer(u32x4 rsrc, int voff_bytes, tg_lds
 // conflicted on every read (measured: SQ_LDS_BANK_CONFLICT = 49 % of SQ_LDS_IDX_ACTIVE).
 __device__ __forceinline__ int swz64(int row) { return ((row >> 2) & 1) << 1; }
 
+#ifndef TG_SG_PRIO
+#define TG_SG_PRIO 0       // experiment switch: wave priority around the MFMA cluster (1), the epilogue (2), the weight-DMA issue (4)
+#endif
 #ifndef TG_SG_NG
 #define TG_SG_NG 2           // k_conv3x3_sg at F=128: stages per barrier (ring = 2*NG slots of 8 KB); measured 2: 138.5, 3: 131.6, 4: 127.1 TFLOP/s
 #endif
@@ -459,6 +462,9 @@ __global__ __launch_bounds__(256, (F == 128 ? (NPT_ == 3 ? 3 : 4) : 2)) void k_c
                 const float* wcur = ws[g % D];
                 if (g + 1 < NST) load_b(b_next, g + 1);
                 __builtin_amdgcn_sched_barrier(0);                       // keep the loads HERE: hipcc sinks them to their use, a stage later
+#if TG_SG_PRIO & 1
+                __builtin_amdgcn_s_setprio(1);
+#endif
                 f32x4 a_cur = *reinterpret_cast<const f32x4*>(wcur + aoff);
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
@@ -471,14 +477,23 @@ __global__ __launch_bounds__(256, (F == 128 ? (NPT_ == 3 ? 3 : 4) : 2)) void k_c
                             acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s4], b_cur[t][s4], acc[ct][t], 0, 0, 0);
                     a_cur = a_next;
                 }
+#if TG_SG_PRIO & 1
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 TG_VMCNT(0);                                             // B fragments of stage g+1 (and any weight pieces): a stage old
 #pragma unroll
                 for (int t = 0; t < NPT; ++t) b_cur[t] = b_next[t];
             }
             TG_BARRIER();                                                // group pp+1 has landed for everybody; the slots of group pp are free
             if (NGS * (pp + 2) < NST) {
+#if TG_SG_PRIO & 4
+                __builtin_amdgcn_s_setprio(2);
+#endif
 #pragma unroll
                 for (int h = 0; h < NGS; ++h) dma_w(NGS * (pp + 2) + h);
+#if TG_SG_PRIO & 4
+                __builtin_amdgcn_s_setprio(0);
+#endif
             }
         }
         int mrow[NPT];
@@ -490,7 +505,13 @@ __global__ __launch_bounds__(256, (F == 128 ? (NPT_ == 3 ? 3 : 4) : 2)) void k_c
 #pragma unroll
             for (int g = 0; g < D; ++g) dma_w(g);
         }
+#if TG_SG_PRIO & 2
+        __builtin_amdgcn_s_setprio(3);
+#endif
         conv_epilogue<F, CT, NPT, (EPI == 1 ? 2 : EPI), EPI == 0, true>(acc, mrow, M, 0, kq, out, res, out2, par);
+#if TG_SG_PRIO & 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (!more) break;
         m0 = next * TM;
         tile_setup();

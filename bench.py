@@ -181,6 +181,11 @@ def parse_args(argv=None):
     ap.add_argument("--stagger", type=int, default=-1,
                     help="spread the boards over this many ply offsets before the warm-up (default: max_step at 9x9, 0 = all "
                          "boards start together, at 19x19)")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="run the boards of a GPU as this many independent groups (own context + HIP stream each, advanced by as many "
+                         "host threads): the groups' kernels overlap on the GPU.  Default 1: one serial chain, the configuration the "
+                         "roofline figures are defined on (with K > 1 launches of different groups share the chip, so per-launch "
+                         "durations are no longer exclusive and `roofline` says so)")
     ap.add_argument("--arena-slots", type=int, default=0,
                     help="32-byte tree slots per game and half arena (default: (3*sims + 256) * (header + actions)); the line reports "
                          "the high-water mark and any truncated tree blocks, so a 19x19 run can be sized for more boards per GPU")
@@ -333,13 +338,18 @@ def main(argv=None):
     from transgo_amd.configure import Config
     from transgo_amd.distributed import gather_harvest
     from transgo_amd.replay_buffer import DeviceReplayMemory
-    from transgo_amd.self_play import BatchedSelfPlay
+    from transgo_amd.self_play import BatchedSelfPlay, GroupedSelfPlay
 
     S = a.board
     cfg = Config(num_simulation=a.sims, num_features=a.filters, num_blocks=a.blocks, board_size=S,
                  max_step=a.max_step or (120 if S == 9 else 450), inference_dtype=a.dtype, network=a.network)
     gpu = local if backend == "nccl" else 0
-    sp = BatchedSelfPlay(cfg, a.games, device=gpu, rank=rank, world=world, arena_slots=a.arena_slots)
+    if a.groups > 1:
+        sp = GroupedSelfPlay(cfg, a.games, groups=a.groups, device=gpu, rank=rank, world=world, arena_slots=a.arena_slots)
+        parts = sp.parts
+    else:
+        sp = BatchedSelfPlay(cfg, a.games, device=gpu, rank=rank, world=world, arena_slots=a.arena_slots)
+        parts = [sp]
     if a.network == "transgo":
         sp.set_weights(model.random_transgo_weights(S, 10, a.filters, seed=1234))
     else:
@@ -352,7 +362,10 @@ def main(argv=None):
     period = a.stagger if a.stagger >= 0 else (cfg.max_step if S == 9 else 0)
     t_st = time.perf_counter()
     if period > 1:
-        stagger(sp, period)
+        if a.groups > 1:
+            sp._each(lambda part: stagger(part, period))
+        else:
+            stagger(sp, period)
     stagger_s = time.perf_counter() - t_st
 
     def barrier():
@@ -363,39 +376,71 @@ def main(argv=None):
     tally = {"games": 0, "positions": 0}
 
     def one_step():
-        h = sp.advance(device=True)
-        for hb in gather_harvest(h, S, 10, dst=0, device_index=gpu):      # rank 0: every rank's finished games
-            mem.append_harvest(hb)
-            tally["games"] += hb.n_games; tally["positions"] += hb.n_positions
+        hs = sp.advance(device=True)
+        for h in (hs if a.groups > 1 else [hs]):                          # one gather per group, the same number on every rank
+            for hb in gather_harvest(h, S, 10, dst=0, device_index=gpu):  # rank 0: every rank's finished games
+                mem.append_harvest(hb)
+                tally["games"] += hb.n_games; tally["positions"] += hb.n_positions
 
     for _ in range(a.warmup):
         one_step()
     tally["games"] = tally["positions"] = 0
-    eng = sp.engine
+    engs = [part.engine for part in parts]
     # event pools sized for ONE step; they are drained into running totals after every step (the stream is idle there: the step
     # ended with the visit-count read-back), so the roofline covers every conv launch of the timed region
-    eng.ctx.call("tg_prof_enable", 1, 8192)
-    eng.ctx.call("tg_prof_enable_tree", 1, 8192)
-    cs0 = ctypes.c_uint64()
-    eng.ctx.call("tg_prof_read_tree", None, None, None, ctypes.byref(cs0))
-    st0 = eng.stats()
+    def all_stats():
+        tot = {}
+        for e in engs:
+            for k, v in e.stats().items():
+                tot[k] = max(tot.get(k, 0), v) if k == "max_slots" else tot.get(k, 0) + v
+        return tot
+
+    def children_scored():
+        n = 0
+        for e in engs:
+            c = ctypes.c_uint64()
+            e.ctx.call("tg_prof_read_tree", None, None, None, ctypes.byref(c))
+            n += c.value
+        return n
+    for e in engs:
+        e.ctx.call("tg_prof_enable", 1, 8192)
+        e.ctx.call("tg_prof_enable_tree", 1, 8192)
+    cs0 = children_scored()
+    st0 = all_stats()
     fin0, drop0 = sp.games_finished, sp.games_dropped
-    sp.phase_s = {}; eng.begin_move_s = 0.0
-    ms, nl, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
-    nskip = ctypes.c_int64()
+    for part in parts:
+        part.phase_s = {}
+    for e in engs:
+        e.begin_move_s = 0.0
+    prof = [dict(ms=ctypes.c_double(), nl=ctypes.c_int64(), fl=ctypes.c_double()) for _ in engs]
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         one_step()
-        eng.ctx.call("tg_prof_read", ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(fl))
-        eng.ctx.call("tg_prof_read_tree", None, None, None, None)
+        for e, pr in zip(engs, prof):
+            e.ctx.call("tg_prof_read", ctypes.byref(pr["ms"]), ctypes.byref(pr["nl"]), ctypes.byref(pr["fl"]))
+            e.ctx.call("tg_prof_read_tree", None, None, None, None)
     barrier()
     dt = time.perf_counter() - t0
-    st1 = eng.stats()
-    eng.ctx.call("tg_prof_read", ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(fl))
-    eng.ctx.call("tg_prof_skipped", ctypes.byref(nskip))
-    cms, ams, nw, cs1 = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64(), ctypes.c_uint64()
-    eng.ctx.call("tg_prof_read_tree", ctypes.byref(cms), ctypes.byref(ams), ctypes.byref(nw), ctypes.byref(cs1))
+    st1 = all_stats()
+    ms_v = nl_v = fl_v = nskip_v = cms_v = ams_v = nw_v = 0
+    for e, pr in zip(engs, prof):
+        e.ctx.call("tg_prof_read", ctypes.byref(pr["ms"]), ctypes.byref(pr["nl"]), ctypes.byref(pr["fl"]))
+        k = ctypes.c_int64(); e.ctx.call("tg_prof_skipped", ctypes.byref(k))
+        c1, a1, w1 = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        e.ctx.call("tg_prof_read_tree", ctypes.byref(c1), ctypes.byref(a1), ctypes.byref(w1), None)
+        ms_v += pr["ms"].value; nl_v += pr["nl"].value; fl_v += pr["fl"].value; nskip_v += k.value
+        cms_v += c1.value; ams_v += a1.value; nw_v += w1.value
+    cs1 = children_scored()
+    class _V:                                    # the names the line below was written with
+        def __init__(self, v): self.value = v
+    ms, nl, fl, nskip, cms, ams, nw, cs0, cs1 = _V(ms_v), _V(nl_v), _V(fl_v), _V(nskip_v), _V(cms_v), _V(ams_v), _V(nw_v), _V(cs0), _V(cs1)
+    eng = engs[0]
+    phase_s = {}
+    for part in parts:
+        for k, v in part.phase_s.items():
+            phase_s[k] = phase_s.get(k, 0.0) + v / len(parts)
+    begin_move_s = sum(e.begin_move_s for e in engs) / len(engs)
 
     sims = st1["sims"] - st0["sims"]; evals = st1["evals"] - st0["evals"]; depth = st1["depth_sum"] - st0["depth_sum"]
     t = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -435,7 +480,9 @@ def main(argv=None):
             "ranks": ranks,
             "config": {"workload": f"{S}x{S} Go self-play, {a.sims} sims/move, {net_name}, "
                                    f"{a.games} concurrent boards per GPU", "boards_per_gpu": a.games,
-                       "parallelism": f"games sharded over {world} GPU(s), no data-path collective",
+                       "parallelism": f"games sharded over {world} GPU(s), no data-path collective" + (
+                           f"; on each GPU {a.groups} independent groups of {a.games // a.groups} boards on their own HIP streams" if a.groups > 1 else ""),
+                       "groups_per_gpu": a.groups,
                        "seeds": "k-th game of slot g on rank r: (k*world + r)*G + g (disjoint per job; not BASELINE.md 4's "
                                 "1000*rank + g, which collides beyond 1000 boards per rank)",
                        "step": "one move of every board (search + move selection + record + re-root) and, for the games it "
@@ -451,7 +498,11 @@ def main(argv=None):
                          "kernel": kernel_name(S, a.filters, a.dtype),
                          "launches": int(nl.value), "launches_not_timed": int(nskip.value),
                          "avg_launch_ms": round(ms.value / max(1, nl.value), 4),
-                         "rank": 0},
+                         "rank": 0,
+                         "exclusive": a.groups == 1,
+                         "exclusive_note": None if a.groups == 1 else
+                         (f"{a.groups} groups launch on {a.groups} streams: conv launches of different groups share the chip, so avg_launch_ms "
+                          "is not an exclusive duration and `achieved` understates the kernel; the groups = 1 line carries the roofline")},
             "roofline_tree": tree,
             "cpu_baseline": cpu,
             "cpu_baseline_c1": cpu_c1,
@@ -470,8 +521,8 @@ def main(argv=None):
                       "tree_errors": st1["errors"], "arena_high_water_slots": st1["max_slots"],
                       "arena_slots_per_half": int(eng.ctx.cfg.arena_slots) or (3 * a.sims + 256) * ((2 if S == 9 else 4) + S * S + 1),
                       "truncated_tree_blocks": st1["truncated_blocks"],
-                      "step_phases_ms": dict({k: round(v / a.steps * 1e3, 2) for k, v in sp.phase_s.items()},
-                                             begin_move_inside_search=round(eng.begin_move_s / a.steps * 1e3, 2)),
+                      "step_phases_ms": dict({k: round(v / a.steps * 1e3, 2) for k, v in phase_s.items()},
+                                             begin_move_inside_search=round(begin_move_s / a.steps * 1e3, 2)),
                       "step_phases_note": "rank 0 wall clock per step: search = root noise (host Dirichlet) + all waves; select = visit "
                                           "counts D2H + pi/move sampling on the host; play = record + re-root kernel + new-root evaluation; "
                                           "game_end = harvest + restart of finished slots (gather/append are outside these four)"},

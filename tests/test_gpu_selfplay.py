@@ -272,3 +272,37 @@ def test_default_actor_takes_a_mainnetwork_state_dict():
     # and the actor loop runs on with it
     actor.continuous_self_play(st, ReplayMemory_Random(cfg), max_moves=2)
     assert st.get_info("now_play_steps") == 2 * G and eng.stats()["errors"] == 0
+
+
+def test_grouped_selfplay_plays_the_same_games():
+    """GroupedSelfPlay: the boards of a GPU as K independent groups on their own contexts / HIP streams, advanced by K host threads
+    (the groups' kernels overlap on the GPU).  Nothing about a game may change: slot g of group k is slot k*G/K + g of the job (same
+    seeds), and a network row does not depend on which rows share its batch -- after every move the root visit counts of all 24
+    games equal the ungrouped engine's bit for bit, and so do the finished games."""
+    from transgo_amd import model
+    from transgo_amd.configure import Config
+    from transgo_amd.self_play import BatchedSelfPlay, GroupedSelfPlay
+    cfg = Config(num_simulation=40, max_step=6, num_features=32, num_blocks=2)
+    sd = model.random_weights(9, 10, 32, 2, seed=9)
+    G, K = 24, 4
+    one = BatchedSelfPlay(cfg, G)
+    one.set_weights(sd)
+    grp = GroupedSelfPlay(cfg, G, groups=K)
+    grp.set_weights(sd)
+    one.start(); grp.start()
+    assert [int(x) for x in one.seeds] == [int(x) for p in grp.parts for x in p.seeds]
+    fin_one, fin_grp = [], []
+    for move in range(7):                                              # one full generation + the first move of the next
+        # search without playing: compare the visit counts the move will be chosen from
+        h1 = one.advance()
+        hs = grp.advance()
+        if h1 is not None:
+            fin_one += [(r.seed, r.winner, r.score, [v.tolist() for v in r.visits]) for r in h1.records()]
+        for h in hs:
+            if h is not None:
+                fin_grp += [(r.seed, r.winner, r.score, [v.tolist() for v in r.visits]) for r in h.records()]
+        v1 = one.engine.root_visits()[0]
+        vg = np.concatenate([p.engine.root_visits()[0] for p in grp.parts])
+        assert np.array_equal(v1, vg), move
+    assert len(fin_one) == G and sorted(fin_one) == sorted(fin_grp)
+    assert grp.stats()["errors"] == 0 and grp.games_finished == one.games_finished == G

@@ -306,3 +306,26 @@ def test_grouped_selfplay_plays_the_same_games():
         assert np.array_equal(v1, vg), move
     assert len(fin_one) == G and sorted(fin_one) == sorted(fin_grp)
     assert grp.stats()["errors"] == 0 and grp.games_finished == one.games_finished == G
+
+
+def test_actor_loop_with_game_groups():
+    """Config.game_groups = K: the actor's boards run as K groups on their own streams; counters, stored tuples and the weight
+    refresh behave as with one group."""
+    from transgo_amd import model
+    from transgo_amd.configure import Config
+    from transgo_amd.replay_buffer import ReplayMemory_Random
+    from transgo_amd.self_play import GroupedSelfPlay, SelfPlay
+    from transgo_amd.shared_storage import SharedStorage
+    cfg = Config(num_simulation=8, max_step=6, num_features=32, num_blocks=2, buffer_size=4096, game_groups=2)
+    st = SharedStorage({"weights": model.random_weights(9, 10, 32, 2), "now_play_steps": 0, "now_play_games": 0,
+                        "now_train_steps": 10 ** 9, "train_play_ratio": 0.075, "adjust_train_play_ratio": True,
+                        "game_total_num": 1e8, "adjust_lr": False, "learn_rate": 1e-4}, cfg)
+    mem = ReplayMemory_Random(cfg)
+    actor = SelfPlay(cfg, n_games=6)
+    assert isinstance(actor.worker, GroupedSelfPlay) and actor.worker.K == 2
+    actor.continuous_self_play(st, mem, max_moves=6)
+    assert st.get_info("now_play_games") == 6 and st.get_info("now_play_steps") == 36
+    assert mem.info()["index"] == 6 * 6 * 8
+    st.set_info({"weights": model.random_weights(9, 10, 32, 2, seed=3), "now_train_steps": 10 ** 9 + 1})
+    actor.continuous_self_play(st, mem, max_moves=1)                   # the refresh reaches every group
+    assert actor.worker.stats()["errors"] == 0

@@ -22,6 +22,7 @@ class Config:
         self.num_blocks = 6                      # tower depth (BASELINE.json "N-block x F-filter")
         self.network = "tower"                   # "tower" | "transgo" (the shipped MainNetwork with attention, model.py:49-76)
         self.concurrent_games = 4096             # boards resident on one GPU
+        self.game_groups = 1                     # K > 1: the boards of a GPU as K independent groups on their own HIP streams (GroupedSelfPlay)
         self.stagger_games = 0                   # T > 1: slot g starts its first game at step g mod T (BatchedSelfPlay.start): games end
                                                  # spread over T steps instead of all on one; 0 = all slots start together
         self.inference_dtype = "f32"             # "f16": fp16 weights/activations, f32 accumulate (BASELINE config 5; towers of 128/256

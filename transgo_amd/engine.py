@@ -249,7 +249,8 @@ class SelfPlayEngine:
         hdr = records.header_bytes(self.S, self.C, ng)
         if device:
             import torch
-            buf = torch.empty(total, dtype=torch.uint8, device=torch.device("cuda", self.device))
+            # zeros, not empty: the layout has alignment padding nobody writes, and the batch is compared / hashed / sent as bytes
+            buf = torch.zeros(total, dtype=torch.uint8, device=torch.device("cuda", self.device))
             host = records.Harvest(self.S, self.C, ng, 0, np.zeros(hdr, np.uint8))        # per-game tables are written on the host
         else:
             buf = np.zeros(total, np.uint8)

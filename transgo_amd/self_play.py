@@ -252,6 +252,32 @@ class GroupedSelfPlay:
         for p in self.parts:
             p.set_weights(state_dict)
 
+    def set_weights_blob(self, blob, background=False):
+        for p in self.parts:
+            p.set_weights_blob(blob, background)
+
+    # what the actor loop reads off its worker (SelfPlay.continuous_self_play)
+    @property
+    def arch(self):
+        return self.parts[0].arch
+
+    @arch.setter
+    def arch(self, a):
+        for p in self.parts:
+            p.arch = a
+
+    @property
+    def filters(self):
+        return self.parts[0].filters
+
+    @property
+    def blocks(self):
+        return self.parts[0].blocks
+
+    @property
+    def last_live(self):
+        return sum(p.last_live for p in self.parts)
+
     def start(self, stagger=0):
         self._each(lambda p: p.start(stagger))
 
@@ -367,7 +393,12 @@ class SelfPlay:
     def __init__(self, config, n_games=None, device=0, rank=0, world=1, evaluator=None):
         self.config = config
         self.n_games = n_games or getattr(config, "concurrent_games", 1024)
-        self.worker = BatchedSelfPlay(config, self.n_games, device=device, rank=rank, world=world, evaluator=evaluator)
+        groups = int(getattr(config, "game_groups", 1) or 1)
+        if groups > 1 and evaluator is None:
+            # the boards as independent groups on their own HIP streams (GroupedSelfPlay): kernels of different groups overlap
+            self.worker = GroupedSelfPlay(config, self.n_games, groups=groups, device=device, rank=rank, world=world)
+        else:
+            self.worker = BatchedSelfPlay(config, self.n_games, device=device, rank=rank, world=world, evaluator=evaluator)
         self._train_steps_seen = None      # storage's now_train_steps when the weights were last fetched
         self._blob_digest = None           # content digest of the packed weights now on the GPU
 
@@ -551,8 +582,12 @@ class SelfPlay:
         while max_moves is None or moves < max_moves:
             start = time.time()
             self._move_prologue(shared_storage_worker, throttle)
-            h = wk.advance(device=on_gpu)
-            batches, live = gather_harvest(h, wk.S, wk.config.encode_state_channels, dst=0, device_index=wk.device, live=wk.last_live)
+            hs = wk.advance(device=on_gpu)
+            batches, live = [], 0
+            for k, h in enumerate(hs if isinstance(hs, list) else [hs]):     # one gather per group: the same number on every rank
+                b, lv = gather_harvest(h, wk.S, wk.config.encode_state_channels, dst=0, device_index=wk.device,
+                                       live=wk.last_live if k == 0 else 0)
+                batches += b; live += lv
             moves += 1
             throttle = False
             if not owner:

@@ -432,9 +432,8 @@ def main(argv=None):
         ms_v += pr["ms"].value; nl_v += pr["nl"].value; fl_v += pr["fl"].value; nskip_v += k.value
         cms_v += c1.value; ams_v += a1.value; nw_v += w1.value
     cs1 = children_scored()
-    class _V:                                    # the names the line below was written with
-        def __init__(self, v): self.value = v
-    ms, nl, fl, nskip, cms, ams, nw, cs0, cs1 = _V(ms_v), _V(nl_v), _V(fl_v), _V(nskip_v), _V(cms_v), _V(ams_v), _V(nw_v), _V(cs0), _V(cs1)
+    from types import SimpleNamespace as _V          # summed over the groups; the line below reads `.value`
+    ms, nl, fl, nskip, cms, ams, nw, cs0, cs1 = (_V(value=v) for v in (ms_v, nl_v, fl_v, nskip_v, cms_v, ams_v, nw_v, cs0, cs1))
     eng = engs[0]
     phase_s = {}
     for part in parts:

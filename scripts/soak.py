@@ -13,7 +13,7 @@ SIMS = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 DTYPE = sys.argv[4] if len(sys.argv) > 4 else "f32"
 S = int(sys.argv[5]) if len(sys.argv) > 5 else 9
 MAXSTEP = int(sys.argv[6]) if len(sys.argv) > 6 else 120
-F, NB = (128, 2) if (DTYPE in ("f16", "f16r") or S == 19) else (32, 2)      # 19x19 is built for 128 and 256 filters
+F, NB = (128, 2) if (DTYPE in ("f16", "f16r", "f32x3") or S == 19) else (32, 2)      # 19x19 is built for 128 and 256 filters
 cfg = Config(num_simulation=SIMS, num_features=F, num_blocks=NB, inference_dtype=DTYPE, board_size=S, max_step=MAXSTEP)
 sp = BatchedSelfPlay(cfg, G)
 sp.set_weights(model.random_weights(S, 10, F, NB, seed=1))

@@ -345,6 +345,9 @@ __device__ __forceinline__ void tg_dma_buffer(u32x4 rsrc, int voff_bytes, tg_lds
 // conflicted on every read (measured: SQ_LDS_BANK_CONFLICT = 49 % of SQ_LDS_IDX_ACTIVE).
 __device__ __forceinline__ int swz64(int row) { return ((row >> 2) & 1) << 1; }
 
+#ifndef TG_H2_XCD
+#define TG_H2_XCD 0        // experiment switch: XCD-contiguous row-tile order in k_conv3x3_h2
+#endif
 #ifndef TG_SG_PERSIST128
 #define TG_SG_PERSIST128 0
 #endif
@@ -678,7 +681,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
     // the COS cout parts of one row tile are blocks b and b+8: same XCD (b % 8), dispatched together, so the slab's second read hits L2
     // Persistent: this workgroup takes blocks bid, bid + gridDim.x, ... (gridDim.x is a multiple of 8*COS, so the cout part co0
     // never changes); blocks whose rows lie past M (the block count is rounded up) are skipped.
-    auto tile_m0 = [&](int b) { return (COS == 1 ? b : (b / (8 * COS)) * 8 + b % 8) * TM; };
+    // TG_H2_XCD: XCD x (= b % 8) takes the contiguous row-tile range [x * tpx, (x + 1) * tpx), tpx = nblk / (8 * COS), so neighbouring
+    // tiles share their slab halos through one L2 (linear order: consecutive tiles sit on consecutive XCDs and every halo is fetched twice)
+    auto tile_m0 = [&](int b) {
+        if (TG_H2_XCD) return ((b % 8) * (nblk / (8 * COS)) + b / (8 * COS)) * TM;
+        return (COS == 1 ? b : (b / (8 * COS)) * 8 + b % 8) * TM;
+    };
     int bid = blockIdx.x;
     const int co0 = COS == 1 ? 0 : ((bid / 8) % COS) * NCO;
     while (bid < nblk && tile_m0(bid) >= M) bid += gridDim.x;
@@ -1486,7 +1494,7 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
             if ((long long)M * F * 4 >= (1ll << 31)) TG_FAIL(ctx, TG_ERR_ARG, "split-precision path: rows * P * F * 4 bytes must stay below 2 GiB per activation buffer");
             const int grid_h = (M + 255) / 256;
             constexpr int COS = F / 128;
-            const int nblk_h2 = COS == 1 ? grid_h : (grid_h + 7) / 8 * 8 * COS;
+            const int nblk_h2 = (COS == 1 && !TG_H2_XCD) ? grid_h : (grid_h + 7) / 8 * 8 * COS;
             const size_t nb = n->blocks.size();
             int g0h = (int)(((size_t)M * 8 + 255) / 256); if (g0h > 65535) g0h = 65535;
             if (n->in_bits) hipLaunchKernelGGL((k_bits_to_rows_h<S>), dim3(g0h), dim3(256), 0, st, n->in_bits, n->in_slot, n->x0h, rows, n->C, n->in_words);
@@ -1524,7 +1532,7 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
             if ((long long)M * F * 2 >= (1ll << 31)) TG_FAIL(ctx, TG_ERR_ARG, "fp16 path: rows * P * F * 2 bytes must stay below 2 GiB per activation buffer");
             const int grid_h = (M + 255) / 256;                                      // 256-row tiles
             constexpr int COS = F / 128;
-            const int nblk_h2 = COS == 1 ? grid_h : (grid_h + 7) / 8 * 8 * COS;      // (row tile, cout part) blocks
+            const int nblk_h2 = (COS == 1 && !TG_H2_XCD) ? grid_h : (grid_h + 7) / 8 * 8 * COS;      // (row tile, cout part) blocks
             // one workgroup per block: the kernel can walk a tile list (grid < nblk), but the hardware dispatcher balances
             // better than a static list -- 512 persistent workgroups measured 0.6-2 % slower
             const int grid_h2 = nblk_h2;

@@ -46,6 +46,46 @@ def test_split_precision_tower_within_1e5_of_torch_f32(S, F, NB, n):
     assert np.allclose(hp.sum(1), 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize("F,n", [(128, 300), (256, 40)])
+def test_split_precision_mainnetwork_with_attention(F, n):
+    """The reference's shipped MainNetwork ("RARRRARRRRAR+P", model.py:49-76) under net_precision 3: its nine residual blocks on
+    the split-precision convs, the Self_Attention layers (trunk and policy head) on the f32 kernels, which hand a residual
+    block that follows its input already split (k_attention_mfma<..., X2O>).  Against the torch restatement that
+    tests/golden/net_transgo_f32.npz pins, and against the exact-f32 HIP path on the same input."""
+    import torch
+    from oracle.net import TransGoMain
+    from transgo_amd.model import HipNetwork, transgo_arch
+    torch.manual_seed(5); torch.set_num_threads(8)
+    net = TransGoMain(9, 10, F).eval()
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+            if hasattr(m, "gamma"):
+                m.gamma.copy_(0.5 + torch.rand(1, generator=g))
+    x = _positions(9, n, 12)
+    with torch.no_grad():
+        p, v, o = [t.numpy() for t in net.main_prediction(torch.from_numpy(x))]
+    sd = {k: t.numpy() for k, t in net.state_dict().items()}
+    h = HipNetwork(9, 10, F, rows_cap=max(8, n), arch=transgo_arch(), precision="f32x3")
+    h.set_weights(sd)
+    hp, hv, ho = h.main_prediction(x)
+    e = [float(np.abs(a - b).max()) for a, b in ((hp, p), (hv, v), (ho, o))]
+    h32 = HipNetwork(9, 10, F, rows_cap=max(8, n), arch=transgo_arch())
+    h32.set_weights(sd)
+    e32 = [float(np.abs(a - b).max()) for a, b in zip(h32.main_prediction(x), (p, v, o))]
+    print(f"f32x3 MainNetwork F={F}: max abs err vs torch f32 policy {e[0]:.2e} value {e[1]:.2e} own {e[2]:.2e} "
+          f"(exact-f32 MFMA path: {e32[0]:.2e} {e32[1]:.2e} {e32[2]:.2e})")
+    assert max(e) < TOL
+    assert np.allclose(hp.sum(1), 1.0, atol=1e-5)
+    # a batch that is not a multiple of the attention kernel's four boards per workgroup, and a single row
+    for k in (1, 7):
+        qp, qv, qo = h.main_prediction(x[:k])
+        assert np.array_equal(qp, hp[:k]) and np.array_equal(qv, hv[:k]) and np.array_equal(qo, ho[:k])
+
+
 def test_split_precision_background_refresh_and_refusals():
     """The weight hand-off (tg_net_load_async -> switch at a boundary) restages the split copies too; widths the fp16 kernels are not
     built for are refused loudly."""

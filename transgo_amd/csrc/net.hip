@@ -1228,7 +1228,8 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
 #ifndef TG_ATT_OCC
 #define TG_ATT_OCC 1
 #endif
-template <int S, int F, int CP>
+// X2O: out2 is the split-precision chain's conv input instead -- fp16 hi + lo of relu(bn1_next(y)), chunk-major (x2_index).
+template <int S, int F, int CP, bool X2O = false>
 __global__ __launch_bounds__(256, TG_ATT_OCC) void k_attention_mfma(const float* __restrict__ qkv, const float* __restrict__ xin,
                                                         float* __restrict__ out, float* __restrict__ out2,
                                                         const float* __restrict__ gamma, const float* __restrict__ bs,
@@ -1358,7 +1359,19 @@ __global__ __launch_bounds__(256, TG_ATT_OCC) void k_attention_mfma(const float*
                     u[q] = z > 0.f ? z : 0.f;
                 }
                 *reinterpret_cast<f32x4*>(out + (size_t)m * F + c) = y;
-                if (out2) *reinterpret_cast<f32x4*>(out2 + f32_sm_index(m, c, M)) = u;
+                if constexpr (X2O) {
+                    if (out2) {
+                        h4 hi, lo;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { hi[q] = (_Float16)u[q]; lo[q] = (_Float16)(u[q] - (float)hi[q]); }
+                        _Float16* const o16 = reinterpret_cast<_Float16*>(out2);
+                        const int c2 = x2_index(c);
+                        *reinterpret_cast<h4*>(o16 + h16_index(m, c2, M)) = hi;
+                        *reinterpret_cast<h4*>(o16 + h16_index(m, c2 + 16, M)) = lo;
+                    }
+                } else {
+                    if (out2) *reinterpret_cast<f32x4*>(out2 + f32_sm_index(m, c, M)) = u;
+                }
             }
         }
     }
@@ -1500,26 +1513,62 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
             if (n->in_bits) hipLaunchKernelGGL((k_bits_to_rows_h<S>), dim3(g0h), dim3(256), 0, st, n->in_bits, n->in_slot, n->x0h, rows, n->C, n->in_words);
             else hipLaunchKernelGGL((k_obs_to_rows_h<S>), dim3(g0h), dim3(256), 0, st, obs, n->x0h, rows, n->C);
             const float* wsc = n->wsc;
-            hipLaunchKernelGGL((k_conv3x3_h2<S, 64, F, 4, false, true>), dim3(nblk_h2), dim3(256), 0, st, (const _Float16*)n->x0h, x, n->act16,
-                               (const float*)nullptr, (const _Float16*)n->stem_h, n->stem.b, nb ? n->blocks[0].s1 : n->s_end,
-                               nb ? n->blocks[0].t1 : n->t_end, M, nblk_h2, wsc + 2 * nb);
-            for (size_t i = 0; i < nb; ++i) {
-                const BlockW& b = n->blocks[i];
-                const bool last = i + 1 == nb;
-                const float* sn = last ? nullptr : n->blocks[i + 1].s1;
-                const float* tn = last ? nullptr : n->blocks[i + 1].t1;
+            // The layer program (attention layers allowed at 9x9): residual blocks on the split-precision convs; a Self_Attention
+            // layer reads and writes the f32 residual stream with the f32 kernels (1x1 q/k/v projection + k_attention_mfma) and,
+            // when a residual block follows, hands it relu(bn1_next(y)) already split (X2O).
+            const size_t nl = n->layers.size();
+            auto next_bn = [&](size_t i, const float** sn, const float** tn) -> bool {   // layer i+1 is a residual block?
+                if (i + 1 < nl && n->layers[i + 1].kind == 0) { const BlockW& nb2 = n->blocks[n->layers[i + 1].ridx]; *sn = nb2.s1; *tn = nb2.t1; return true; }
+                *sn = nullptr; *tn = nullptr; return false;
+            };
+            constexpr int WQ = F / 4 + F / 4 + F;
+            auto attention_x2 = [&](const AttW& a, const float* xin, float* xout, const float* ps, const float* pt, _Float16* o2,
+                                    const float* sn, const float* tn) {
+                if constexpr (S == 9) {
+                    if (ps)
+                        hipLaunchKernelGGL((k_conv3x3<S, F, WQ, true, 2, 1>), dim3(grid), dim3(256), 0, st, xin, n->bufQ,
+                                           (const float*)nullptr, a.qkv.w, a.qkv.b, ps, pt, M);
+                    else
+                        hipLaunchKernelGGL((k_conv3x3<S, F, WQ, false, 2, 1>), dim3(grid), dim3(256), 0, st, xin, n->bufQ,
+                                           (const float*)nullptr, a.qkv.w, a.qkv.b, (const float*)nullptr, (const float*)nullptr, M);
+                    hipLaunchKernelGGL((k_attention_mfma<S, F, 2, true>), dim3((rows + 3) / 4), dim3(256), 0, st, (const float*)n->bufQ, xin, xout,
+                                       reinterpret_cast<float*>(o2), a.gamma, a.s, a.t, ps, pt, sn, tn, rows);
+                }
+            };
+            const float* s0 = nullptr; const float* t0 = nullptr;
+            const bool act0 = nl && n->layers[0].kind == 0;
+            if (act0) { s0 = n->blocks[n->layers[0].ridx].s1; t0 = n->blocks[n->layers[0].ridx].t1; }
+            hipLaunchKernelGGL((k_conv3x3_h2<S, 64, F, 4, false, true>), dim3(nblk_h2), dim3(256), 0, st, (const _Float16*)n->x0h, x,
+                               act0 ? n->act16 : (_Float16*)nullptr, (const float*)nullptr, (const _Float16*)n->stem_h, n->stem.b, s0, t0,
+                               M, nblk_h2, wsc + 2 * nb);
+            for (size_t i = 0; i < nl; ++i) {
+                const Layer& L = n->layers[i];
+                const float* sn; const float* tn;
+                const bool act = next_bn(i, &sn, &tn);
+                if (L.kind == 1) {
+                    attention_x2(L.a, x, y, nullptr, nullptr, act ? n->act16 : (_Float16*)nullptr, sn, tn);
+                    float* t = x; x = y; y = t;
+                    continue;
+                }
+                const BlockW& b = n->blocks[L.ridx];
                 { ProfScope ps(n, st, conv_flops);
                   hipLaunchKernelGGL((k_conv3x3_h2<S, 2 * F, F, 0, false, true>), dim3(nblk_h2), dim3(256), 0, st, (const _Float16*)n->act16,
                                      (float*)nullptr, n->h16, (const float*)nullptr, b.h1, b.c1.b, (const float*)nullptr, (const float*)nullptr, M, nblk_h2,
-                                     wsc + 2 * i); }
+                                     wsc + 2 * L.ridx); }
                 { ProfScope ps(n, st, conv_flops);
                   hipLaunchKernelGGL((k_conv3x3_h2<S, 2 * F, F, 1, false, true>), dim3(nblk_h2), dim3(256), 0, st, (const _Float16*)n->h16,
-                                     y, last ? (_Float16*)nullptr : n->act16, (const float*)x, b.h2, b.c2.b, sn, tn, M, nblk_h2, wsc + 2 * i + 1); }
+                                     y, act ? n->act16 : (_Float16*)nullptr, (const float*)x, b.h2, b.c2.b, sn, tn, M, nblk_h2, wsc + 2 * L.ridx + 1); }
                 float* t = x; x = y; y = t;
             }
             // the head conv is 16 couts wide (one MFMA tile): the f32 kernel reads the f32 residual stream and activates while staging
             head_conv(x, n->hc, n->head_g, n->head, n->s_end, n->t_end);
-            hipLaunchKernelGGL((k_heads<S>), dim3((rows + HeadRows<S>::N - 1) / HeadRows<S>::N), dim3(256), 0, st, (const float*)n->hc, (const float*)n->hc, n->w_vo, n->b_vo,
+            const float* hca3 = n->hc;
+            if (n->pol_att) {                              // attention in the policy head (model.py:72,106-107), f32 kernels
+                attention_x2(n->patt, x, y, n->s_end, n->t_end, (_Float16*)nullptr, (const float*)nullptr, (const float*)nullptr);
+                head_conv(y, n->hca, n->head_ag, n->head_a, nullptr, nullptr);
+                hca3 = n->hca;
+            }
+            hipLaunchKernelGGL((k_heads<S>), dim3((rows + HeadRows<S>::N - 1) / HeadRows<S>::N), dim3(256), 0, st, (const float*)n->hc, hca3, n->w_vo, n->b_vo,
                                n->w_v, n->b_v, n->w_o, n->b_o, n->w_a, n->b_a, policy, value, own, rows);
             TG_HIP(ctx, hipGetLastError());
             return TG_OK;
@@ -1893,8 +1942,8 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
     const size_t P = (size_t)S * S, A = P + 1, Wq = (size_t)F / 4 * 2 + F;
     const bool any_att = pol || trunk.find('A') != std::string::npos;
     int NB = 0; for (char c : trunk) NB += c == 'R';
-    if (prec >= 1 && (any_att || (F != 128 && F != 256)))
-        TG_FAIL(ctx, TG_ERR_ARG, "net_precision 1 / 2 / 3 (fp16 matrix cores) is built for attention-free towers with 128 or 256 filters");
+    if (prec >= 1 && ((any_att && !(prec == 3 && S == 9)) || (F != 128 && F != 256)))
+        TG_FAIL(ctx, TG_ERR_ARG, "net_precision 1 / 2 (fp16 matrix cores) is built for attention-free towers with 128 or 256 filters; 3 (split precision) also takes attention layers at 9x9");
     if (!n) {
         n = new Net();
         e->net = n;

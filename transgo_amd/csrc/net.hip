@@ -29,7 +29,8 @@ namespace tg {
 struct ConvW { const float* w; const float* b; };
 struct BlockW { const float* s1; const float* t1; ConvW c1; ConvW c2; const float* g1; const float* g2;
                 const _Float16* h1; const _Float16* h2; };   // g1/g2: stage-ordered f32, h1/h2: stage-ordered fp16 copies of c1.w / c2.w
-struct AttW { ConvW qkv; const float* gamma; const float* s; const float* t; };      // Self_Attention, model.py:288-315
+struct AttW { ConvW qkv; const float* gamma; const float* s; const float* t;          // Self_Attention, model.py:288-315
+              const _Float16* x3w = nullptr; const float* x3sc = nullptr; };          // split q|k|v weights (LDS image) + 2^-s of k_attention_x3
 struct Layer { int kind; int ridx; AttW a; };                                         // kind 0: residual block blocks[ridx]; 1: attention
 
 struct Net {
@@ -62,7 +63,8 @@ struct Net {
     // running -- and the next forward that finds it complete rebinds.  `swapped` orders a later refill of the retired set behind
     // every kernel that may still read it.
     struct WeightSet { float* blob = nullptr; float* wstage = nullptr; _Float16* wh = nullptr; _Float16* stem_h = nullptr; _Float16* head_h = nullptr;
-                       float* wsc = nullptr; float* head_g = nullptr; float* head_ag = nullptr; };   // head_g / head_ag: k_head_gemm copies of head / head_a
+                       float* wsc = nullptr; float* head_g = nullptr; float* head_ag = nullptr;
+                       _Float16* att_h = nullptr; float* att_sc = nullptr; };                          // k_attention_x3: per attention layer, split weight image + scale   // head_g / head_ag: k_head_gemm copies of head / head_a
     WeightSet sets[2]; int active = 0; bool pending = false;
     hipStream_t side = nullptr; hipEvent_t loaded = nullptr, swapped = nullptr; float* pinned = nullptr;
     // profiling of the dominant kernel (3x3 conv F->F) with HIP events on the launch stream
@@ -75,6 +77,8 @@ struct Net {
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using h2 = __attribute__((ext_vector_type(2))) _Float16;
 using h8 = __attribute__((ext_vector_type(8))) _Float16;
 using h4 = __attribute__((ext_vector_type(4))) _Float16;
 __device__ __forceinline__ int tid0() { return (int)threadIdx.x; }
@@ -1377,6 +1381,407 @@ __global__ __launch_bounds__(256, TG_ATT_OCC) void k_attention_mfma(const float*
     }
 }
 
+// Self_Attention as ONE kernel for the split-precision chain (net_precision 3, F = 128, 9x9): the q/k/v 1x1 projection is computed
+// inside the per-board core, on the fp16 matrix cores in split precision, and never goes through memory (the two-kernel form
+// moves 62 KB of q|k|v per board out and back in: at 16 k boards the pair took 0.61 + 0.70 ms, 23 % of a MainNetwork wave).
+//   * the split weights of the layer ([F/16 groups][W couts][hi 16 | lo 16], 64-B rows XOR-swizzled like the conv's stage tiles,
+//     scaled by 2^s; k_restage_att_split) sit in LDS for the life of a persistent workgroup (96 KB, one workgroup of 4 waves per CU);
+//   * one wave per board, as in k_attention_mfma.  x fragments are built from the f32 residual stream on the fly: lane (j, kq) loads
+//     8 channels of row j and keeps their fp16 hi (kq < 2) or lo (kq >= 2) halves -- the [a_hi | a_lo] operand of a K = 32 step;
+//   * phase A: q^T and k^T for the whole board, as D[c][pos] tiles -- which ARE the A / B operand layouts of the energy GEMM's f32
+//     16x16x4 steps (k index = 4*(lane >> 4) + r).  A three-stage stream over the 16-channel groups: group g on the matrix cores,
+//     group g+1 being split (VALU work in the shadow of the MFMAs), group g+2's loads in flight;
+//   * phase B, per block of 16 rows i (tm): v for those rows and all channels as D[pos][c] tiles -- the A operand layout of the
+//     output GEMM -- from the block's x fragments (second and last read of x, from L2); the block's 16 x 96 energies; softmax on
+//     the accumulator tiles (a row is complete within the block); out[c][j] += v[i][c] attention[i][j] into accumulators that
+//     cover all channels.  Nothing but those accumulators outlives a block, so the 36 energy tiles of k_attention_mfma never exist
+//     at once and x is split twice per board, not once per channel pass.
+//   * epilogue as k_attention_mfma: y = relu(bn(gamma * out + x)) row-major, and the next residual block's split input.
+// Per board: 1152 K=32 fp16 steps (projection) + 1296 f32 16x16x4 steps (exact-f32 energy and output GEMMs); HBM: x in once, y (+ the
+// next block's split input) out.  PRO: x is relu(x*ps + pt) first (attention in the policy head, model.py:94,106).
+// one butterfly step of a reduction over the 16 lanes of a DPP row (= the 16 columns j of one lane group kq), without LDS traffic:
+// steps 0, 1 exchange within quads (lane ^ 1, lane ^ 2); steps 2, 3 mirror the half row / the row, which pairs quad with quad and
+// half with half -- the values are uniform within those by then, so the result equals the xor butterfly's, in the same order
+__device__ __forceinline__ float row16_step(float v, int step) {
+    const int x = __builtin_bit_cast(int, v);
+    int r;
+    switch (step) {
+        case 0: r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false); break;      // quad_perm [1,0,3,2]
+        case 1: r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false); break;      // quad_perm [2,3,0,1]
+        case 2: r = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false); break;     // row_half_mirror
+        default: r = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false); break;    // row_mirror
+    }
+    return __builtin_bit_cast(float, r);
+}
+#ifndef TG_ATT_IGLP
+#define TG_ATT_IGLP 1
+#endif
+#if TG_ATT_IGLP
+// NM MFMAs with KV VALU instructions (the split of the next group) in the shadow of each
+#define TG_ATT_SCHED(NM, KV) do { _Pragma("unroll") for (int i_ = 0; i_ < (NM); ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); \
+                                  __builtin_amdgcn_sched_group_barrier(0x002, (KV), 0); } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TG_ATT_SCHED(NM, KV) __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifdef TG_ATT_STAMP
+// diagnostic build: phase stamps (s_memtime, 100 MHz) of the third board of wave 0 of workgroup 0, PRO = false launches
+__device__ unsigned long long g_att_stamp[32];
+#define TG_ASTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (!PRO && blockIdx.x == 0 && wave == 0 && nboard == 2 && lane == 0) g_att_stamp[i] = __builtin_readcyclecounter(); \
+                          __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TG_ASTAMP(i) do { } while (0)
+#endif
+#ifndef TG_ATT_TOUCH
+#define TG_ATT_TOUCH 1
+#endif
+template <int S, int F, bool PRO>
+__global__ __launch_bounds__(256, 1) void k_attention_x3(const float* __restrict__ xin, float* __restrict__ out, _Float16* __restrict__ out2,
+                                                         const _Float16* __restrict__ wimg, const float* __restrict__ qb,
+                                                         const float* __restrict__ wsc_p, const float* __restrict__ gamma,
+                                                         const float* __restrict__ bs, const float* __restrict__ bt,
+                                                         const float* __restrict__ ps, const float* __restrict__ pt,
+                                                         const float* __restrict__ s2, const float* __restrict__ t2, int rows) {
+    constexpr int P = S * S, FQ = F / 4, W = 2 * FQ + F, NT = (P + 15) / 16, CT = F / 16, NG = F / 16, NSUB = FQ / 16;
+    static_assert(P <= 96 && FQ % 16 == 0 && NG % 2 == 0, "attention tile geometry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
+    _Float16* const wl = reinterpret_cast<_Float16*>(att_smem);                       // [NG][W][32]
+    for (int i = threadIdx.x; i < NG * W * 4; i += 256) reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(wimg)[i];
+    // per-channel parameters behind the image: q|k|v bias [W], then bn scale / shift, next block's bn1 scale / shift, prologue scale /
+    // shift [F each].  Read from LDS, they neither pin registers across the board loop nor queue behind the epilogue's stores (vector
+    // memory loads and stores share the in-order vmcnt)
+    float* const prm = reinterpret_cast<float*>(att_smem + (size_t)NG * W * 64);
+    for (int i = threadIdx.x; i < W; i += 256) prm[i] = qb[i];
+    for (int i = threadIdx.x; i < F; i += 256) {
+        prm[W + i] = bs[i]; prm[W + F + i] = bt[i];
+        prm[W + 2 * F + i] = out2 ? s2[i] : 1.f; prm[W + 3 * F + i] = out2 ? t2[i] : 0.f;
+        prm[W + 4 * F + i] = PRO ? ps[i] : 1.f; prm[W + 5 * F + i] = PRO ? pt[i] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: board pointers stay in SGPRs
+    const int j = lane & 15, kq = lane >> 4;
+    const float lo_neg = kq >> 1 ? -1.f : -0.f;                                      // -1: this lane carries the lo halves of x
+    const unsigned chx = (kq & 1) * 8;
+    const int whi = j * 32 + (((kq & 1) ^ swz64(j)) << 3), wlo = j * 32 + (((2 + (kq & 1)) ^ swz64(j)) << 3);
+    // ds_read offsets are 16-bit: the image's upper half gets its own (opaque) base so that no address needs a register of its own
+    int upper = NG / 2 * W * 32;
+    asm volatile("" : "+v"(upper));
+    const _Float16* const wl1 = wl + upper;
+    auto wgroup = [&](int g) { return g < NG / 2 ? wl + g * W * 32 : wl1 + (g - NG / 2) * W * 32; };
+    const float wsc = wsc_p[0];
+    const int M = rows * P;
+    // Addresses: tile t of a board starts 16 rows = 16*F floats further (a scalar add on the board pointer); within the tile lane j
+    // takes row j -- except in the last tile, where rows past the board clamp to its last row.  Four per-lane byte offsets serve
+    // every access: {first five tiles, last tile} x {8-channel column of the projection reads, 4-channel column of the D tiles}.
+    constexpr int LASTR = P - 1 - (NT - 1) * 16;                                     // last valid row of the last tile
+    const unsigned rowA = (unsigned)j * F * 4u, rowB = (unsigned)(j <= LASTR ? j : LASTR) * F * 4u;
+    const unsigned xoA = rowA + chx * 4u, xoB = rowB + chx * 4u, eoA = rowA + kq * 16u, eoB = rowB + kq * 16u;
+    const unsigned hoA = ((unsigned)(kq >> 1) * M + j) * 16u + (kq & 1) * 8u;        // split chunk-major output, + t*256 per tile
+    auto tile = [](const float* board, int t) { return board + t * 16 * F; };
+    auto ld16 = [](const float* base, unsigned byte_off) { return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off); };
+    // 8 channels of one row -> this lane's half of the split fragment
+    const float* l_ps = nullptr; const float* l_pt = nullptr;                          // set per board (LDS parameter block)
+    struct Pro { f32x4 sc[2], sh[2]; };                                               // prologue scale / shift of this lane's 8 channels of a group
+    auto pro_of = [&](int g) {
+        Pro p{};
+        if constexpr (PRO) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { p.sc[h] = *reinterpret_cast<const f32x4*>(l_ps + g * 16 + chx + 4 * h); p.sh[h] = *reinterpret_cast<const f32x4*>(l_pt + g * 16 + chx + 4 * h); }
+        }
+        return p;
+    };
+    auto split8 = [&](const f32x4 (&src)[2], const Pro& pr) -> h8 {
+        h8 xf;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            f32x2 v = {src[e >> 2][e & 3], src[e >> 2][(e & 3) + 1]};
+            if constexpr (PRO) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { const float w = v[q] * pr.sc[e >> 2][(e & 3) + q] + pr.sh[e >> 2][(e & 3) + q]; v[q] = w > 0.f ? w : 0.f; }
+            }
+            const f32x2 hi = __builtin_convertvector(__builtin_convertvector(v, h2), f32x2);
+            // hi lanes (lo_neg = -0): half(v); lo lanes (lo_neg = -1): half(v - hi), the product is exact either way
+            const f32x2 d = {__builtin_fmaf(lo_neg, hi[0], v[0]), __builtin_fmaf(lo_neg, hi[1], v[1])};
+            const h2 o = __builtin_convertvector(d, h2);
+            xf[e] = o[0]; xf[e + 1] = o[1];
+        }
+        return xf;
+    };
+    f32x4 rawA[NT][2], rawB[NT][2];                                                  // phase A stream: one group of all six tiles each
+    h8 xfA[NT], xfB[NT];
+    // (the lane offsets are made opaque where they are used: hoisted out of the board loop in their 64-bit form they are spilled, and the
+    // loads then take full VGPR addresses reloaded from scratch -- behind whatever the wave has in flight)
+    auto issue = [&](const float* xb, int g, f32x4 (&dst)[NT][2]) {
+        unsigned oa = xoA, ob = xoB;
+        asm volatile("" : "+v"(oa), "+v"(ob));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            dst[t][0] = ld16(tile(xb, t), (t + 1 < NT ? oa : ob) + g * 64);
+            dst[t][1] = ld16(tile(xb, t), (t + 1 < NT ? oa : ob) + g * 64 + 16);
+        }
+    };
+    auto split = [&](const f32x4 (&src)[NT][2], int g, h8 (&xf)[NT]) {
+        const Pro pr = pro_of(g);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xf[t] = split8(src[t], pr);
+    };
+    int b = blockIdx.x * 4 + wave;
+    if (b >= rows) return;
+    { const float* xb0 = xin + (size_t)b * P * F; issue(xb0, 0, rawB); issue(xb0, 1, rawA); }
+    int nboard = 0;
+    for (; b < rows; b += gridDim.x * 4, ++nboard) {
+        const float* xb = xin + (size_t)b * P * F;
+        // opaque per board: LDS is read-only from here on, so every parameter read would otherwise be hoisted out of the board loop
+        // (and pin, then spill, ~150 registers)
+        unsigned popq = 0;
+        asm volatile("" : "+v"(popq));                                                // (an opaque OFFSET: the pointer keeps its LDS address space)
+        const float* const l_qb = prm + popq;
+        const float* const l_bs = l_qb + W; const float* const l_bt = l_bs + F;
+        const float* const l_s2 = l_bt + F; const float* const l_t2 = l_s2 + F; l_ps = l_t2 + F; l_pt = l_ps + F;
+        TG_ASTAMP(0);
+        // ---- phase A: q^T and k^T, [c][pos] tiles ----
+        f32x4 qk[2 * NSUB][NT];
+#pragma unroll
+        for (int ct = 0; ct < 2 * NSUB; ++ct)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) qk[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto mfma_qk = [&](int g, const h8 (&xf)[NT]) {
+#pragma unroll
+            for (int ct = 0; ct < 2 * NSUB; ++ct) {
+                const _Float16* wr = wgroup(g) + ct * 16 * 32;
+                const h8 ah = *reinterpret_cast<const h8*>(wr + whi), al = *reinterpret_cast<const h8*>(wr + wlo);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) qk[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xf[t], qk[ct][t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) qk[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xf[t], qk[ct][t], 0, 0, 0);
+            }
+        };
+        split(rawB, 0, xfA);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < NG; g += 2) {
+            if (g + 2 < NG) issue(xb, g + 2, rawB);
+            mfma_qk(g, xfA);
+            split(rawA, g + 1, xfB);
+            TG_ATT_SCHED(2 * NSUB * NT * 2, 3);
+            if (g + 3 < NG) issue(xb, g + 3, rawA);
+            mfma_qk(g + 1, xfB);
+            if (g + 2 < NG) split(rawB, g + 2, xfA);
+            TG_ATT_SCHED(2 * NSUB * NT * 2, 3);
+            if (g == 0) TG_ASTAMP(29);
+        }
+        TG_ASTAMP(1);
+        // ---- phase B, block tm = rows i in [16 tm, 16 tm + 16) ----
+        f32x4 rv[NG][2];                                                             // the block's x rows, all groups
+        auto issue_rows = [&](int tm) {
+            unsigned o = tm + 1 < NT ? xoA : xoB;
+            asm volatile("" : "+v"(o));
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                rv[g][0] = ld16(tile(xb, tm), o + g * 64);
+                rv[g][1] = ld16(tile(xb, tm), o + g * 64 + 16);
+            }
+        };
+        issue_rows(0);
+#pragma unroll
+        for (int ct = 0; ct < 2 * NSUB; ++ct) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(l_qb + ct * 16 + kq * 4);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) qk[ct][t] = qk[ct][t] * wsc + bq;
+        }
+        // The output accumulators START from the residual x (PRO: relu(x*ps + pt)) and v carries the factor gamma, so that they end
+        // as gamma * out + x and the epilogue has no loads at all: a load queued behind the epilogue's stores would wait for their
+        // acknowledgements (vmcnt is in order), and did -- 30 % of a board's time in the first version.  D tile: row = channel
+        // ct*16 + kq*4 + r, column = position tn*16 + j.  These loads (third read of x, L2) are not needed before the first block's
+        // output GEMM.
+        const float gam = gamma[0];
+        f32x4 acc[CT][NT];
+        unsigned eoa = eoA, eob = eoB;
+        asm volatile("" : "+v"(eoa), "+v"(eob));
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn) {
+                f32x4 xv = ld16(tile(xb, tn), (tn + 1 < NT ? eoa : eob) + ct * 64);
+                if constexpr (PRO) {
+                    const f32x4 vps = *reinterpret_cast<const f32x4*>(l_ps + ct * 16 + kq * 4), vpt = *reinterpret_cast<const f32x4*>(l_pt + ct * 16 + kq * 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const float w = xv[q] * vps[q] + vpt[q]; xv[q] = w > 0.f ? w : 0.f; }
+                }
+                acc[ct][tn] = xv;
+                // PRO: the values pass through VALU registers; fenced two channel tiles at a time so that 48 loads' worth of them is
+                // never live at once
+                if constexpr (PRO) { if (tn == NT - 1 && (ct & 1)) __builtin_amdgcn_sched_barrier(0); }
+            }
+        // next board's rows towards L2 now (one dword per 128-B line, results unused): phase A is the first touch of a board's x and
+        // its loads run only one group ahead of their use -- from HBM that was 17 % of a board's time
+        const int bnx = b + gridDim.x * 4;
+        const float* const xnext = xin + (size_t)(bnx < rows ? bnx : b) * P * F;
+#if TG_ATT_TOUCH
+        // as LDS-DMA into a scratch KB of this wave: no destination registers, nothing ever waits for them
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const unsigned lo = (unsigned)(lane + 64 * i) * 128u, off = lo < (unsigned)(P * F * 4 - 16) ? lo : (unsigned)(P * F * 4 - 16);
+            tg_dma_global(xnext, (int)off, (tg_lds_void*)(&att_smem[(size_t)NG * W * 64 + (W + 6 * F) * 4 + wave * 1024]));
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        TG_ASTAMP(27);
+#pragma unroll
+        for (int tm = 0; tm < NT; ++tm) {
+            // v for the block: D[pos][c], all channel tiles
+            f32x4 va[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) va[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // weight fragments: eight in flight, each slot refilled (for the next half-group) right behind the MFMA that used it; the
+            // fences and group barriers keep that distance (left alone, the scheduler sinks every read next to its MFMA and the wave
+            // sits on LDS latency 128 times per block)
+            h8 wf[CT];
+            auto wslot = [&](int hg, int ct) {                                       // half-group hg = 2*g + (0: hi, 1: lo)
+                return *reinterpret_cast<const h8*>(wgroup(hg >> 1) + (2 * FQ + ct * 16) * 32 + ((hg & 1) ? wlo : whi));
+            };
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) wf[ct] = wslot(0, ct);
+            h8 xf = split8(rv[0], pro_of(0)), xfn = xf;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int hg = 0; hg < 2 * NG; ++hg) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    va[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf, wf[ct], va[ct], 0, 0, 0);
+                    if (hg + 1 < 2 * NG) wf[ct] = wslot(hg + 1, ct);
+                }
+                if ((hg & 1) == 0 && hg + 2 < 2 * NG) xfn = split8(rv[hg / 2 + 1], pro_of(hg / 2 + 1));   // next group's fragment, in the MFMA shadow
+#if TG_ATT_IGLP
+#pragma unroll
+                for (int i_ = 0; i_ < CT; ++i_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                if (hg & 1) xf = xfn;
+            }
+            TG_ASTAMP(2 + 4 * tm);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tm + 1 < NT) issue_rows(tm + 1);                                      // lands during the block's energy / output GEMMs
+            __builtin_amdgcn_sched_barrier(0);                                       // (kept here: sunk to the block's end they are waited for at once)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) va[ct] = (va[ct] * wsc + l_qb[2 * FQ + ct * 16 + j]) * gam;
+            // energies of the block (exact f32): e[tn] = q[tm] . k[tn]
+            f32x4 e[NT];
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn) e[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int tn = 0; tn < NT; ++tn)
+                        e[tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(qk[sub][tm][s4], qk[NSUB + sub][tn][s4], e[tn], 0, 0, 0);
+            TG_ASTAMP(3 + 4 * tm);
+            // softmax over j (columns) for the rows i = tm*16 + kq*4 + r
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int tn = 0; tn < NT; ++tn) if (tn * 16 + j < P) mx = e[tn][r] > mx ? e[tn][r] : mx;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) { const float t = row16_step(mx, o); mx = t > mx ? t : mx; }
+                float sum = 0.f;
+#pragma unroll
+                for (int tn = 0; tn < NT; ++tn) {
+                    const float v = tn * 16 + j < P ? __expf(e[tn][r] - mx) : 0.f;        // v_exp_f32: ~1e-7 relative, tolerance is 1e-3
+                    e[tn][r] = v; sum += v;
+                }
+#pragma unroll
+                for (int o = 0; o < 4; ++o) sum += row16_step(sum, o);
+                const float inv = (tm * 16 + kq * 4 + r < P) ? 1.f / sum : 0.f;     // rows past the board contribute nothing below
+#pragma unroll
+                for (int tn = 0; tn < NT; ++tn) e[tn][r] *= inv;
+            }
+            TG_ASTAMP(4 + 4 * tm);
+            // out[c][j] += v[i][c] attention[i][j]: k-step r covers rows i = tm*16 + kq*4 + r; of the last block only the steps that
+            // touch a row < P exist
+            constexpr int LASTS = P - (NT - 1) * 16, NS_LAST = LASTS < 4 ? LASTS : 4;
+            const int ns = tm + 1 < NT ? 4 : NS_LAST;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r >= ns) continue;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int tn = 0; tn < NT; ++tn)
+                        acc[ct][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[ct][r], e[tn][r], acc[ct][tn], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            TG_ASTAMP(5 + 4 * tm);
+        }
+        // ---- epilogue.  D tile: row = channel ct*16 + kq*4 + r, column = position tn*16 + j ----
+        // every address = a per-board scalar base + one of six per-lane byte offsets + a compile-time constant.  Loads are kept
+        // AHEAD of the stores in issue order (a load queued behind stores waits for their acknowledgements): the next board's first
+        // two groups go out before the first store, and the residual is already inside the accumulators.
+        {
+            issue(xnext, 0, rawB); issue(xnext, 1, rawA);                             // unconditional (last board: its own rows again)
+        }
+        char* const yb = reinterpret_cast<char*>(out + (size_t)b * P * F);
+        // opaque per board: hoisted out of the board loop, the 64-bit forms of these offsets would be spilled -- and a spill reload in
+        // here queues behind the stores
+        unsigned eoE = eoA, hoE = hoA;
+        asm volatile("" : "+v"(eoE), "+v"(hoE));
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = ct * 16 + kq * 4;
+            const f32x4 vbs = *reinterpret_cast<const f32x4*>(l_bs + c), vbt = *reinterpret_cast<const f32x4*>(l_bt + c);
+            const f32x4 vs2 = *reinterpret_cast<const f32x4*>(l_s2 + c), vt2 = *reinterpret_cast<const f32x4*>(l_t2 + c);
+            // split output: element (m, x2_index(c)) of the chunk-major tensor = chunk plane ct*4 + (kq >> 1) (lo: + 2), row m, half (kq & 1)*4
+            char* const hb = reinterpret_cast<char*>(out2) + ((size_t)ct * 4 * M + (size_t)b * P) * 16;
+            char* const lb = hb + (size_t)2 * M * 16;
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn) {
+                if (tn * 16 + j >= P) continue;
+                f32x4 y, u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float w = acc[ct][tn][q] * vbs[q] + vbt[q];
+                    y[q] = w > 0.f ? w : 0.f;
+                    const float z = y[q] * vs2[q] + vt2[q];
+                    u[q] = z > 0.f ? z : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(yb + tn * 16 * F * 4 + (eoE + ct * 64)) = y;
+                if (out2) {
+                    h4 hi, lo;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { hi[q] = (_Float16)u[q]; lo[q] = (_Float16)(u[q] - (float)hi[q]); }
+                    *reinterpret_cast<h4*>(hb + (hoE + tn * 256)) = hi;
+                    *reinterpret_cast<h4*>(lb + (hoE + tn * 256)) = lo;
+                }
+            }
+            if (ct == 3) TG_ASTAMP(28);
+        }
+        TG_ASTAMP(26);
+    }
+    TG_VMCNT(0);                                                                     // the last board's touches and stores
+}
+
+// the LDS image of k_attention_x3: dst[g][cout][32] = [hi of channels g*16..+15 | lo of the same] of w[cout][F] * 2^s, the four
+// 16-B chunks of a row XOR-swizzled by swz64(cout) (the fragment reads of the kernel undo it); wsc_out = 2^-s
+__global__ __launch_bounds__(256) void k_restage_att_split(const float* __restrict__ w, _Float16* __restrict__ dst, float* __restrict__ wsc_out,
+                                                           const unsigned* __restrict__ maxbits, int W, int F) {
+    const unsigned mb = maxbits[0];
+    int sh = mb ? 14 - ((int)((mb >> 23) & 0xffu) - 127) : 0;
+    sh = sh < -60 ? -60 : sh > 60 ? 60 : sh;
+    const float scale = ldexpf(1.f, sh);
+    if (blockIdx.x == 0 && threadIdx.x == 0) wsc_out[0] = ldexpf(1.f, -sh);
+    const int total = F / 16 * W * 32;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int k = i & 31, r = (i >> 5) % W, g = (i >> 5) / W;
+        const int kk = (((k >> 3) ^ swz64(r)) << 3) + (k & 7);                       // logical position of this physical slot
+        const float v = w[(size_t)r * F + g * 16 + (kk & 15)] * scale;
+        const _Float16 hi = (_Float16)v;
+        dst[i] = (kk & 16) ? (_Float16)(v - (float)hi) : hi;
+    }
+}
+
 // Heads after the 3x3 head convs (hc[row][p][16]: channels 0-1 value/own, 2-5 policy; BN+ReLU already applied).
 // HR rows per workgroup (8 at 9x9, 2 at 19x19): the dense weights (fc_act alone is 4P x A floats = 106 KB at 9x9) are read once per workgroup and used
 // for all its rows -- with one row per workgroup the kernel moved 1.7 GB of L2 -> CU traffic per 16384 rows.  Every output is the
@@ -1524,6 +1929,19 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
             constexpr int WQ = F / 4 + F / 4 + F;
             auto attention_x2 = [&](const AttW& a, const float* xin, float* xout, const float* ps, const float* pt, _Float16* o2,
                                     const float* sn, const float* tn) {
+                if constexpr (S == 9 && F == 128) {
+                    // one kernel per attention block: q/k/v projected inside the core, in split precision (TG_ATT_X3=0: the pair below)
+                    static const bool fused = !(getenv("TG_ATT_X3") && atoi(getenv("TG_ATT_X3")) == 0);
+                    if (fused && a.x3w) {
+                        constexpr int lds3 = (int)(sizeof(_Float16) * F / 16 * WQ * 32 + sizeof(float) * (WQ + 6 * F) + 4096);   // image, parameters, touch scratch
+                        const int nwg = (rows + 3) / 4 < 256 ? (rows + 3) / 4 : 256;
+                        if (ps) hipLaunchKernelGGL((k_attention_x3<S, F, true>), dim3(nwg), dim3(256), lds3, st, xin, xout, o2, a.x3w, a.qkv.b, a.x3sc,
+                                                   a.gamma, a.s, a.t, ps, pt, sn, tn, rows);
+                        else hipLaunchKernelGGL((k_attention_x3<S, F, false>), dim3(nwg), dim3(256), lds3, st, xin, xout, o2, a.x3w, a.qkv.b, a.x3sc,
+                                                a.gamma, a.s, a.t, ps, pt, sn, tn, rows);
+                        return;
+                    }
+                }
                 if constexpr (S == 9) {
                     if (ps)
                         hipLaunchKernelGGL((k_conv3x3<S, F, WQ, true, 2, 1>), dim3(grid), dim3(256), 0, st, xin, n->bufQ,
@@ -1813,7 +2231,10 @@ void bind_weights(Net* n, int k) {
     n->blocks.assign(n->NB, BlockW{});
     n->layers.clear();
     const size_t per = 9 * (size_t)F * F;
-    int ri = 0;
+    int ri = 0, ai = 0;
+    int n_att = pol ? 1 : 0; for (char c : trunk) n_att += c == 'A';
+    const size_t att_img = (size_t)F / 16 * Wq * 32;                  // halfs per attention layer (k_attention_x3's LDS image)
+    auto bind_x3 = [&](AttW& a) { if (w.att_h) { a.x3w = w.att_h + (size_t)ai * att_img; a.x3sc = w.att_sc + ai; } ++ai; };
     for (char c : trunk) {
         Layer L; L.kind = c == 'A'; L.ridx = -1; L.a = AttW{};
         if (c == 'R') {
@@ -1826,12 +2247,13 @@ void bind_weights(Net* n, int k) {
             b.h1 = w.wh ? w.wh + (size_t)(2 * ri) * perh : nullptr; b.h2 = w.wh ? w.wh + (size_t)(2 * ri + 1) * perh : nullptr;
             L.ridx = ri++;
         } else {
-            take_att(L.a);
+            take_att(L.a); bind_x3(L.a);
         }
         n->layers.push_back(L);
     }
     n->s_end = take(F); n->t_end = take(F);
-    if (pol) { take_att(n->patt); n->head_a.w = take(9 * 16 * (size_t)F); n->head_a.b = take(16); }
+    if (pol) { take_att(n->patt); bind_x3(n->patt); n->head_a.w = take(9 * 16 * (size_t)F); n->head_a.b = take(16); }
+    (void)n_att;
     n->head.w = take(9 * 16 * (size_t)F); n->head.b = take(16);
     n->w_vo = take(2 * P * 64); n->b_vo = take(64); n->w_v = take(64); n->b_v = take(1);
     n->w_o = take(64 * P); n->b_o = take(P); n->w_a = take(4 * P * A); n->b_a = take(A);
@@ -1865,6 +2287,19 @@ int fill_weight_set(tg_ctx* ctx, Net* n, int k, const float* blob, hipStream_t s
                 hipLaunchKernelGGL(k_restage_split, dim3(1024), dim3(256), 0, st, w, const_cast<_Float16*>(h ? b.h2 : b.h1), n->sets[k].wsc + ci,
                                    (const unsigned*)(mx + ci), F, F, F / 16, 1);
                 ++ci;
+            }
+        }
+        if (n->sets[k].att_h) {                                                       // fused attention layers: split q|k|v weights
+            std::vector<const AttW*> atts;
+            for (const Layer& L : view.layers) if (L.kind == 1) atts.push_back(&L.a);
+            if (n->pol_att) atts.push_back(&view.patt);
+            const int Wq = F / 4 * 2 + F;
+            unsigned* amx = reinterpret_cast<unsigned*>(n->sets[k].att_sc) + atts.size();
+            TG_HIP(ctx, hipMemsetAsync(amx, 0, sizeof(unsigned) * atts.size(), st));
+            for (size_t a = 0; a < atts.size(); ++a) {
+                hipLaunchKernelGGL(k_absmax, dim3(64), dim3(256), 0, st, atts[a]->qkv.w, (size_t)Wq * F, amx + a);
+                hipLaunchKernelGGL(k_restage_att_split, dim3(256), dim3(256), 0, st, atts[a]->qkv.w, const_cast<_Float16*>(atts[a]->x3w),
+                                   const_cast<float*>(atts[a]->x3sc), (const unsigned*)(amx + a), Wq, F);
             }
         }
         hipLaunchKernelGGL(k_absmax, dim3(64), dim3(256), 0, st, view.stem.w, (size_t)9 * F * 16, mx + ci);
@@ -1973,6 +2408,11 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
             if (prec >= 1) {
                 TG_HIP(ctx, hipMalloc((void**)&w.wh, sizeof(_Float16) * wcopy * (prec == 3 ? 2 : 1)));
                 if (prec == 3) TG_HIP(ctx, hipMalloc((void**)&w.wsc, sizeof(float) * 2 * (size_t)(2 * NB + 1)));
+                if (prec == 3 && any_att && F == 128 && S == 9) {                    // k_attention_x3 (its weight image must fit LDS)
+                    size_t n_att = pol ? 1 : 0; for (char c : trunk) n_att += c == 'A';
+                    TG_HIP(ctx, hipMalloc((void**)&w.att_h, sizeof(_Float16) * n_att * ((size_t)F / 16 * Wq * 32)));
+                    TG_HIP(ctx, hipMalloc((void**)&w.att_sc, sizeof(float) * 2 * n_att));
+                }
                 TG_HIP(ctx, hipMalloc((void**)&w.stem_h, sizeof(_Float16) * 9 * (size_t)F * 64));
                 TG_HIP(ctx, hipMalloc((void**)&w.head_h, sizeof(_Float16) * 9 * 16 * (size_t)F));
             }
@@ -1988,6 +2428,11 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
         TG_HIP(ctx, hipEventRecord(n->swapped, ctx->stream));
         TG_HIP(ctx, hipHostMalloc((void**)&n->pinned, sizeof(float) * n_floats, hipHostMallocDefault));
         n->active = 1;                                    // the load below fills set 0 and makes it the live one
+        if (prec == 3 && any_att && F == 128 && S == 9) {
+            const int lds3 = (int)(sizeof(_Float16) * (size_t)F / 16 * Wq * 32 + sizeof(float) * (Wq + 6 * (size_t)F) + 4096);
+            TG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention_x3<9, 128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3));
+            TG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention_x3<9, 128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3));
+        }
         if (any_att) {
             const size_t lds = sizeof(float) * (P * Wq + P * (P + 1));
             if (lds <= 160 * 1024) {
@@ -2059,13 +2504,20 @@ int tg_net_load_poll(tg_ctx* ctx, int wait, int* pending) {
     return rc;
 }
 
+#ifdef TG_ATT_STAMP
+int tg_debug_att_stamps(unsigned long long* out, int n) {
+    if (n > 32) n = 32;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_att_stamp), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
+
 void tg_net_destroy(tg_ctx* ctx) {
     if (!ctx || !ctx->eng || !ctx->eng->net) return;
     Net* n = ctx->eng->net;
     if (n->pending) (void)hipEventSynchronize(n->loaded);
     void* ptrs[] = {n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->bufQ, n->hca, n->bufAct, n->act16, n->h16, n->x0h, n->tile_ctr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    for (Net::WeightSet& w : n->sets) { void* q[] = {w.blob, w.wstage, w.wh, w.stem_h, w.head_h, w.wsc, w.head_g, w.head_ag}; for (void* p : q) if (p) (void)hipFree(p); }
+    for (Net::WeightSet& w : n->sets) { void* q[] = {w.blob, w.wstage, w.wh, w.stem_h, w.head_h, w.wsc, w.head_g, w.head_ag, w.att_h, w.att_sc}; for (void* p : q) if (p) (void)hipFree(p); }
     if (n->side) (void)hipStreamDestroy(n->side);
     if (n->loaded) (void)hipEventDestroy(n->loaded);
     if (n->swapped) (void)hipEventDestroy(n->swapped);

@@ -1217,6 +1217,20 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
     }
 }
 
+// one butterfly step of a reduction over the 16 lanes of a DPP row (= the 16 columns j of one lane group kq), without LDS traffic:
+// steps 0, 1 exchange within quads (lane ^ 1, lane ^ 2); steps 2, 3 mirror the half row / the row, which pairs quad with quad and
+// half with half -- the values are uniform within those by then, so the result equals the xor butterfly's, in the same order
+__device__ __forceinline__ float row16_step(float v, int step) {
+    const int x = __builtin_bit_cast(int, v);
+    int r;
+    switch (step) {
+        case 0: r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false); break;      // quad_perm [1,0,3,2]
+        case 1: r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false); break;      // quad_perm [2,3,0,1]
+        case 2: r = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false); break;     // row_half_mirror
+        default: r = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false); break;    // row_mirror
+    }
+    return __builtin_bit_cast(float, r);
+}
 // The same Self_Attention core on the matrix cores (F = 64, 128, 256 at 9x9): ONE WAVE PER BOARD, everything between the q/k/v
 // projection and the block's output stays in registers.
 //   GEMM 1  energy[i][j] = sum_c q[i][c] k[j][c]        (P x P x F/4; 6 x 6 tiles of 16 x 16, P = 81 padded to 96)
@@ -1284,7 +1298,7 @@ __global__ __launch_bounds__(256, TG_ATT_OCC) void k_attention_mfma(const float*
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn) if (tn * 16 + j < P) mx = e[tm][tn][r] > mx ? e[tm][tn][r] : mx;
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { const float t = __shfl_xor(mx, o); mx = t > mx ? t : mx; }
+            for (int o = 0; o < 4; ++o) { const float t = row16_step(mx, o); mx = t > mx ? t : mx; }   // DPP: no LDS round trips
             float sum = 0.f;
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn) {
@@ -1292,7 +1306,7 @@ __global__ __launch_bounds__(256, TG_ATT_OCC) void k_attention_mfma(const float*
                 e[tm][tn][r] = v; sum += v;
             }
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
+            for (int o = 0; o < 4; ++o) sum += row16_step(sum, o);
             const float inv = (tm * 16 + kq * 4 + r < P) ? 1.f / sum : 0.f;     // rows past the board contribute nothing to GEMM 2
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn) e[tm][tn][r] *= inv;
@@ -1326,6 +1340,27 @@ __global__ __launch_bounds__(256, TG_ATT_OCC) void k_attention_mfma(const float*
         for (int cp = 0; cp < CP; ++cp)
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn) acc[cp][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the pass's residual rows are requested BEFORE its MFMAs: they queue behind the previous pass's stores (vmcnt is in order)
+        // and have the whole output GEMM to get past them; requested in the epilogue they were waited for at once
+        f32x4 x[CP][NT];
+#pragma unroll
+        for (int cp = 0; cp < CP; ++cp)
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn) {
+                const int p = tn * 16 + j < P ? tn * 16 + j : P - 1;
+                x[cp][tn] = *reinterpret_cast<const f32x4*>(xin + (size_t)(b * P + p) * F + (c0 + cp) * 16 + kq * 4);
+            }
+        // ... and so are the pass's per-channel parameters
+        f32x4 vbs[CP], vbt[CP], vps[CP], vpt[CP], vs2[CP], vt2[CP];
+#pragma unroll
+        for (int cp = 0; cp < CP; ++cp) {
+            const int c = (c0 + cp) * 16 + kq * 4;
+            vbs[cp] = *reinterpret_cast<const f32x4*>(bs + c); vbt[cp] = *reinterpret_cast<const f32x4*>(bt + c);
+            vps[cp] = f32x4{1.f, 1.f, 1.f, 1.f}; vpt[cp] = f32x4{0.f, 0.f, 0.f, 0.f}; vs2[cp] = vps[cp]; vt2[cp] = vpt[cp];
+            if (ps) { vps[cp] = *reinterpret_cast<const f32x4*>(ps + c); vpt[cp] = *reinterpret_cast<const f32x4*>(pt + c); }
+            if (out2) { vs2[cp] = *reinterpret_cast<const f32x4*>(s2 + c); vt2[cp] = *reinterpret_cast<const f32x4*>(t2 + c); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk)
 #pragma unroll
@@ -1337,16 +1372,6 @@ __global__ __launch_bounds__(256, TG_ATT_OCC) void k_attention_mfma(const float*
 #pragma unroll
         for (int cp = 0; cp < CP; ++cp) {
             const int c = (c0 + cp) * 16 + kq * 4;
-            const f32x4 vbs = *reinterpret_cast<const f32x4*>(bs + c), vbt = *reinterpret_cast<const f32x4*>(bt + c);
-            f32x4 vps = f32x4{1.f, 1.f, 1.f, 1.f}, vpt = f32x4{0.f, 0.f, 0.f, 0.f}, vs2 = vps, vt2 = vpt;
-            if (ps) { vps = *reinterpret_cast<const f32x4*>(ps + c); vpt = *reinterpret_cast<const f32x4*>(pt + c); }
-            if (out2) { vs2 = *reinterpret_cast<const f32x4*>(s2 + c); vt2 = *reinterpret_cast<const f32x4*>(t2 + c); }
-            f32x4 x[NT];
-#pragma unroll
-            for (int tn = 0; tn < NT; ++tn) {
-                const int p = tn * 16 + j < P ? tn * 16 + j : P - 1;
-                x[tn] = *reinterpret_cast<const f32x4*>(xin + (size_t)(b * P + p) * F + c);
-            }
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn) {
                 const int p = tn * 16 + j;
@@ -1355,11 +1380,11 @@ __global__ __launch_bounds__(256, TG_ATT_OCC) void k_attention_mfma(const float*
                 f32x4 y, u;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float xv = x[tn][q];
-                    if (ps) { xv = xv * vps[q] + vpt[q]; xv = xv > 0.f ? xv : 0.f; }
-                    const float w = (g * acc[cp][tn][q] + xv) * vbs[q] + vbt[q];
+                    float xv = x[cp][tn][q];
+                    if (ps) { xv = xv * vps[cp][q] + vpt[cp][q]; xv = xv > 0.f ? xv : 0.f; }
+                    const float w = (g * acc[cp][tn][q] + xv) * vbs[cp][q] + vbt[cp][q];
                     y[q] = w > 0.f ? w : 0.f;
-                    const float z = y[q] * vs2[q] + vt2[q];
+                    const float z = y[q] * vs2[cp][q] + vt2[cp][q];
                     u[q] = z > 0.f ? z : 0.f;
                 }
                 *reinterpret_cast<f32x4*>(out + (size_t)m * F + c) = y;
@@ -1399,20 +1424,6 @@ __global__ __launch_bounds__(256, TG_ATT_OCC) void k_attention_mfma(const float*
 //   * epilogue as k_attention_mfma: y = relu(bn(gamma * out + x)) row-major, and the next residual block's split input.
 // Per board: 1152 K=32 fp16 steps (projection) + 1296 f32 16x16x4 steps (exact-f32 energy and output GEMMs); HBM: x in once, y (+ the
 // next block's split input) out.  PRO: x is relu(x*ps + pt) first (attention in the policy head, model.py:94,106).
-// one butterfly step of a reduction over the 16 lanes of a DPP row (= the 16 columns j of one lane group kq), without LDS traffic:
-// steps 0, 1 exchange within quads (lane ^ 1, lane ^ 2); steps 2, 3 mirror the half row / the row, which pairs quad with quad and
-// half with half -- the values are uniform within those by then, so the result equals the xor butterfly's, in the same order
-__device__ __forceinline__ float row16_step(float v, int step) {
-    const int x = __builtin_bit_cast(int, v);
-    int r;
-    switch (step) {
-        case 0: r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false); break;      // quad_perm [1,0,3,2]
-        case 1: r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false); break;      // quad_perm [2,3,0,1]
-        case 2: r = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false); break;     // row_half_mirror
-        default: r = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false); break;    // row_mirror
-    }
-    return __builtin_bit_cast(float, r);
-}
 #ifndef TG_ATT_IGLP
 #define TG_ATT_IGLP 1
 #endif

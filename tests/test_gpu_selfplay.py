@@ -216,8 +216,11 @@ def test_staggered_start_spreads_game_ends_without_changing_games():
         assert all(np.array_equal(a, b) for a, b in zip(q.observations, r.observations))
 
 
-def test_default_actor_takes_a_mainnetwork_state_dict():
-    """What the reference trainer publishes is a MainNetwork state_dict (model.py:49-76: 9 residual + 3 attention blocks, attention
+@pytest.mark.parametrize("dtype", ["f32", "f32x3"])
+def test_default_actor_takes_a_mainnetwork_state_dict(dtype):
+    """(f32x3: the same through the opt-in split-precision mode -- residual blocks on the split convs, every attention block one
+    fused kernel, k_attention_x3 -- whose outputs sit as close to the torch network as the exact-f32 path's.)
+    What the reference trainer publishes is a MainNetwork state_dict (model.py:49-76: 9 residual + 3 attention blocks, attention
     policy head).  A DEFAULT-configured actor (tower layout) handed that dict through the storage must switch layouts by the key
     names and search with it: one searched move of every game, visit counts equal to the oracle search driving the torch
     restatement of MainNetwork with the same weights and seeds (networks agree to ~1e-7, so allow one near-tie to split)."""
@@ -241,7 +244,7 @@ def test_default_actor_takes_a_mainnetwork_state_dict():
             if hasattr(m, "gamma"):
                 m.gamma.copy_(0.5 + torch.rand(1, generator=gen))
     sd = {k: t.numpy() for k, t in net.state_dict().items()}
-    cfg = Config(num_simulation=24, max_step=30, buffer_size=1024)            # everything else: the reference defaults (tower, 128)
+    cfg = Config(num_simulation=24, max_step=30, buffer_size=1024, inference_dtype=dtype)   # everything else: the reference defaults (tower, 128)
     assert getattr(cfg, "network", "tower") == "tower"
     G = 4
     actor = SelfPlay(cfg, n_games=G)
@@ -267,7 +270,7 @@ def test_default_actor_takes_a_mainnetwork_state_dict():
         raw = np.array([o.root.kids[i].n if i in o.root.kids else 0 for i in range(82)])
         assert raw.sum() == vis[g].sum() and np.array_equal(obs, ob[g])
         same += int(np.array_equal(raw, vis[g]))
-    print(f"MainNetwork through a default actor: {same}/{G} first-move visit vectors identical to the oracle's")
+    print(f"MainNetwork through a default actor ({dtype}): {same}/{G} first-move visit vectors identical to the oracle's")
     assert same >= G - 1
     # and the actor loop runs on with it
     actor.continuous_self_play(st, ReplayMemory_Random(cfg), max_moves=2)

@@ -335,6 +335,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
     if (lane == 0) {
         d.game_nslot[g] = nslot;
         c->n_paths = npaths; c->free_slot = free_slot; c->error |= err;
+        if (free_slot > c->hw_slot) c->hw_slot = free_slot;
         c->sims += sims; c->depth_sum += depth_sum; c->evals += evals; c->tie_draws += rng.draws; c->child_sum += child_sum;
         d.rng[g].pos = rng.pos;
         if (err) { atomicAdd(&d.counters[CNT_ERRORS], 1); c->searching = 0; c->active = 0; }
@@ -1195,7 +1196,7 @@ int tg_sp_stats(tg_ctx* ctx, uint64_t* sims, uint64_t* evals, uint64_t* depth_su
     uint64_t s = 0, ev = 0, ds = 0, td = 0; int32_t er = 0, ms = 0;
     for (const GameCtl& c : h) {
         s += c.sims; ev += c.evals; ds += c.depth_sum; td += c.tie_draws;
-        er += c.error ? 1 : 0; ms = c.free_slot > ms ? c.free_slot : ms;
+        er += c.error ? 1 : 0; ms = c.hw_slot > ms ? c.hw_slot : ms; ms = c.free_slot > ms ? c.free_slot : ms;   // a true high-water, not the current fill
     }
     if (sims) *sims = s; if (evals) *evals = ev; if (depth_sum) *depth_sum = ds; if (tie_draws) *tie_draws = td;
     if (errors) *errors = er; if (max_slots) *max_slots = ms;

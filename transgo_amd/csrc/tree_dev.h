@@ -52,7 +52,7 @@ struct GameCtl {
     int32_t error;        // sticky: 1 arena overflow, 2 depth overflow, 4 bad action
     int32_t searching;    // begin_move issued
     int32_t moves;        // moves played in this game = entries of its device-side record (self_play.py:917-926)
-    int32_t pad0;
+    int32_t hw_slot;      // largest free_slot this slot has reached (high-water of its half arena, cumulative like the counters below)
     unsigned long long sims;        // completed backups (terminal ones included)
     unsigned long long evals;       // leaves sent to the evaluator
     unsigned long long depth_sum;   // sum of selection depths

@@ -344,6 +344,10 @@ def main(argv=None):
     cfg = Config(num_simulation=a.sims, num_features=a.filters, num_blocks=a.blocks, board_size=S,
                  max_step=a.max_step or (120 if S == 9 else 450), inference_dtype=a.dtype, network=a.network)
     gpu = local if backend == "nccl" else 0
+    if a.network == "transgo" and not a.arena_slots:
+        # the shipped MainNetwork's policies are peaked even at random init: at the default arena 0.5 % of the game-moves lose kept
+        # sub-tree blocks at re-rooting (counted in truncated_tree_blocks; DESIGN.md 3 "Sizing") -- twice the default holds them all
+        a.arena_slots = 2 * (3 * a.sims + 256) * ((2 if S == 9 else 4) + S * S + 1)
     if a.groups > 1:
         sp = GroupedSelfPlay(cfg, a.games, groups=a.groups, device=gpu, rank=rank, world=world, arena_slots=a.arena_slots)
         parts = sp.parts

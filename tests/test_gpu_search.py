@@ -215,10 +215,13 @@ def test_peaked_policy_full_games_stay_inside_the_default_arena():
     from transgo_amd.self_play import BatchedSelfPlay
     cfg = Config(num_simulation=96, max_step=60)
     sp = BatchedSelfPlay(cfg, 8, evaluator=evaluators.spike)
-    fin = []
+    fin, marks = [], []
     for _ in range(64):
         fin += sp.step()
+        marks.append(sp.engine.stats()["max_slots"])
     st = sp.engine.stats()
+    # max_slots is a high-water mark (per-slot maximum over the run, surviving the games' restarts), not the current fill
+    assert all(b >= a for a, b in zip(marks, marks[1:])) and marks[-1] > 0
     print("peaked policy: arena high-water", st["max_slots"], "truncated blocks", st["truncated_blocks"], "finished", len(fin))
     assert st["errors"] == 0 and sp.games_dropped == 0 and len(fin) >= 8
     assert all(len(r.players) == len(r.pis) >= 1 for r in fin)

@@ -84,6 +84,19 @@ def test_split_precision_mainnetwork_with_attention(F, n):
     for k in (1, 7):
         qp, qv, qo = h.main_prediction(x[:k])
         assert np.array_equal(qp, hp[:k]) and np.array_equal(qv, hv[:k]) and np.array_equal(qo, ho[:k])
+    if F == 128:
+        # more boards than the fused attention kernel has waves (256 workgroups x 4): every wave walks several boards, with the next
+        # board's rows requested while the current one is stored -- against the exact-f32 HIP path on the same batch (both sit
+        # ~1e-7 from torch), and row for row against the small batch above (a board's result does not depend on its neighbours)
+        nb = 2 * 1024 + 131
+        xb = np.concatenate([x, _positions(9, nb - n, 13)])
+        hb = HipNetwork(9, 10, F, rows_cap=nb, arch=transgo_arch(), precision="f32x3"); hb.set_weights(sd)
+        hb32 = HipNetwork(9, 10, F, rows_cap=nb, arch=transgo_arch()); hb32.set_weights(sd)
+        bp, bv, bo = hb.main_prediction(xb)
+        eb = [float(np.abs(a - b).max()) for a, b in zip((bp, bv, bo), hb32.main_prediction(xb))]
+        print(f"f32x3 MainNetwork F={F}, {nb} boards: max abs difference to the exact-f32 HIP path {eb[0]:.2e} {eb[1]:.2e} {eb[2]:.2e}")
+        assert max(eb) < TOL
+        assert np.array_equal(bp[:n], hp) and np.array_equal(bv[:n], hv) and np.array_equal(bo[:n], ho)
 
 
 def test_split_precision_background_refresh_and_refusals():

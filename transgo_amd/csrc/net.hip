@@ -1599,30 +1599,17 @@ __global__ __launch_bounds__(256, 1) void k_attention_x3(const float* __restrict
 #pragma unroll
             for (int t = 0; t < NT; ++t) qk[ct][t] = qk[ct][t] * wsc + bq;
         }
-        // The output accumulators START from the residual x (PRO: relu(x*ps + pt)) and v carries the factor gamma, so that they end
-        // as gamma * out + x and the epilogue has no loads at all: a load queued behind the epilogue's stores would wait for their
-        // acknowledgements (vmcnt is in order), and did -- 30 % of a board's time in the first version.  D tile: row = channel
-        // ct*16 + kq*4 + r, column = position tn*16 + j.  These loads (third read of x, L2) are not needed before the first block's
-        // output GEMM.
+        // The residual x (PRO: relu(x*ps + pt)) is ADDED INTO the output accumulators, column tile tn in row block tm = tn, and v
+        // carries the factor gamma, so that they end as gamma * out + x and the epilogue has no loads at all: a load queued behind
+        // the epilogue's stores would wait for their acknowledgements (vmcnt is in order), and did -- 30 % of a board's time in the
+        // first version.  Taken in block tn, the residual rows are the lines that block's own row loads have just brought in (read
+        // up front for all tiles they were a third trip to HBM: 2.17 GB of reads per launch against 0.67 GB of x).
         const float gam = gamma[0];
         f32x4 acc[CT][NT];
-        unsigned eoa = eoA, eob = eoB;
-        asm volatile("" : "+v"(eoa), "+v"(eob));
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int tn = 0; tn < NT; ++tn) {
-                f32x4 xv = ld16(tile(xb, tn), (tn + 1 < NT ? eoa : eob) + ct * 64);
-                if constexpr (PRO) {
-                    const f32x4 vps = *reinterpret_cast<const f32x4*>(l_ps + ct * 16 + kq * 4), vpt = *reinterpret_cast<const f32x4*>(l_pt + ct * 16 + kq * 4);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { const float w = xv[q] * vps[q] + vpt[q]; xv[q] = w > 0.f ? w : 0.f; }
-                }
-                acc[ct][tn] = xv;
-                // PRO: the values pass through VALU registers; fenced two channel tiles at a time so that 48 loads' worth of them is
-                // never live at once
-                if constexpr (PRO) { if (tn == NT - 1 && (ct & 1)) __builtin_amdgcn_sched_barrier(0); }
-            }
+            for (int tn = 0; tn < NT; ++tn) acc[ct][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
         // next board's rows towards L2 now (one dword per 128-B line, results unused): phase A is the first touch of a board's x and
         // its loads run only one group ahead of their use -- from HBM that was 17 % of a board's time
         const int bnx = b + gridDim.x * 4;
@@ -1675,6 +1662,14 @@ __global__ __launch_bounds__(256, 1) void k_attention_x3(const float* __restrict
             TG_ASTAMP(2 + 4 * tm);
             __builtin_amdgcn_sched_barrier(0);
             if (tm + 1 < NT) issue_rows(tm + 1);                                      // lands during the block's energy / output GEMMs
+            // the residual rows of column tile tm, D layout (row = channel ct*16 + kq*4 + r, column = position tm*16 + j)
+            f32x4 xa[CT];
+            {
+                unsigned o = tm + 1 < NT ? eoA : eoB;
+                asm volatile("" : "+v"(o));
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) xa[ct] = ld16(tile(xb, tm), o + ct * 64);
+            }
             __builtin_amdgcn_sched_barrier(0);                                       // (kept here: sunk to the block's end they are waited for at once)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) va[ct] = (va[ct] * wsc + l_qb[2 * FQ + ct * 16 + j]) * gam;
@@ -1723,6 +1718,16 @@ __global__ __launch_bounds__(256, 1) void k_attention_x3(const float* __restrict
 #pragma unroll
                     for (int tn = 0; tn < NT; ++tn)
                         acc[ct][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[ct][r], e[tn][r], acc[ct][tn], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                f32x4 xv = xa[ct];
+                if constexpr (PRO) {
+                    const f32x4 vps = *reinterpret_cast<const f32x4*>(l_ps + ct * 16 + kq * 4), vpt = *reinterpret_cast<const f32x4*>(l_pt + ct * 16 + kq * 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const float w = xv[q] * vps[q] + vpt[q]; xv[q] = w > 0.f ? w : 0.f; }
+                }
+                acc[ct][tm] = acc[ct][tm] + xv;
             }
             __builtin_amdgcn_sched_barrier(0);
             TG_ASTAMP(5 + 4 * tm);

@@ -1661,8 +1661,8 @@ __global__ __launch_bounds__(256, 1) void k_attention_x3(const float* __restrict
             }
             TG_ASTAMP(2 + 4 * tm);
             __builtin_amdgcn_sched_barrier(0);
-            if (tm + 1 < NT) issue_rows(tm + 1);                                      // lands during the block's energy / output GEMMs
-            // the residual rows of column tile tm, D layout (row = channel ct*16 + kq*4 + r, column = position tm*16 + j)
+            // the residual rows of column tile tm, D layout (row = channel ct*16 + kq*4 + r, column = position tm*16 + j): requested BEFORE
+            // the next block's rows (they are cache hits and must not queue behind loads that go to HBM)
             f32x4 xa[CT];
             {
                 unsigned o = tm + 1 < NT ? eoA : eoB;
@@ -1670,6 +1670,7 @@ __global__ __launch_bounds__(256, 1) void k_attention_x3(const float* __restrict
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) xa[ct] = ld16(tile(xb, tm), o + ct * 64);
             }
+            if (tm + 1 < NT) issue_rows(tm + 1);                                      // lands during the block's energy / output GEMMs
             __builtin_amdgcn_sched_barrier(0);                                       // (kept here: sunk to the block's end they are waited for at once)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) va[ct] = (va[ct] * wsc + l_qb[2 * FQ + ct * 16 + j]) * gam;

@@ -148,7 +148,8 @@ def load_into(ctx, sd, board_size, encode_dim, filters, blocks=None, rows_cap=0,
 
 
 # tg_config.net_precision: "f16" = fp16 weights/activations in HBM and LDS with f32 accumulation and an f32 residual stream
-# (BASELINE config 5); attention-free towers with 128 or 256 filters only -- anything else is refused by tg_net_load.
+# (BASELINE config 5); attention-free towers with 128 or 256 filters only -- anything else is refused by tg_net_load.  "f32x3" also
+# takes attention layers at 9x9 (the shipped MainNetwork; its attention blocks run as one fused kernel each at 128 filters).
 PRECISIONS = {"f32": 0, "f16": 1, "f16r": 2, "f32x3": 3}     # f16r: fp16 residual stream as well; f32x3: split precision (both opt-in)
 
 

@@ -1417,13 +1417,19 @@ __global__ __launch_bounds__(256, TG_ATT_OCC) void k_attention_mfma(const float*
 //     16x16x4 steps (k index = 4*(lane >> 4) + r).  A three-stage stream over the 16-channel groups: group g on the matrix cores,
 //     group g+1 being split (VALU work in the shadow of the MFMAs), group g+2's loads in flight;
 //   * phase B, per block of 16 rows i (tm): v for those rows and all channels as D[pos][c] tiles -- the A operand layout of the
-//     output GEMM -- from the block's x fragments (second and last read of x, from L2); the block's 16 x 96 energies; softmax on
-//     the accumulator tiles (a row is complete within the block); out[c][j] += v[i][c] attention[i][j] into accumulators that
-//     cover all channels.  Nothing but those accumulators outlives a block, so the 36 energy tiles of k_attention_mfma never exist
-//     at once and x is split twice per board, not once per channel pass.
-//   * epilogue as k_attention_mfma: y = relu(bn(gamma * out + x)) row-major, and the next residual block's split input.
-// Per board: 1152 K=32 fp16 steps (projection) + 1296 f32 16x16x4 steps (exact-f32 energy and output GEMMs); HBM: x in once, y (+ the
-// next block's split input) out.  PRO: x is relu(x*ps + pt) first (attention in the policy head, model.py:94,106).
+//     output GEMM -- from the block's x rows (second pass over x; measured, it comes from HBM again: a board's 41 KB do not survive
+//     in an L2 shared by 128 boards in flight); the block's 16 x 96 energies; softmax on the accumulator tiles with DPP row
+//     reductions (a row is complete within the block); out[c][j] += (gamma v)[i][c] attention[i][j] into accumulators that cover all
+//     channels and also take the residual x of column tile tm in block tm (from the lines the block's row loads just fetched).
+//     Nothing but those accumulators outlives a block, so the 36 energy tiles of k_attention_mfma never exist at once and x is
+//     split twice per board, not once per channel pass.
+//   * epilogue: y = relu(bn(acc)) row-major and the next residual block's split input -- stores only (a load in here would queue
+//     behind the stores: vmcnt is in order); the next board's first two groups are requested before the first store, its lines
+//     were touched towards L2 (LDS-DMA into a scratch KB) at the start of phase B.
+// Per board: 1152 K=32 fp16 steps (projection) + 1296 f32 16x16x4 steps (exact-f32 energy and output GEMMs) = 59 k cycles of MFMA;
+// measured 130 k cycles per board (0.98 ms per 16 k boards; MFMA pipe 40 % busy).  PRO: x is relu(x*ps + pt) first (attention in
+// the policy head, model.py:94,106).  Diagnostics: -DTG_ATT_STAMP (phase stamps, scripts/stamp_att.py), TG_ATT_X3=0 (the two-kernel
+// form), -DTG_ATT_TOUCH=0, -DTG_ATT_IGLP=0.
 #ifndef TG_ATT_IGLP
 #define TG_ATT_IGLP 1
 #endif

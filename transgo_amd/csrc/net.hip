@@ -1350,8 +1350,11 @@ __global__ __launch_bounds__(256, TG_ATT_OCC) void k_attention_mfma(const float*
                 const int p = tn * 16 + j < P ? tn * 16 + j : P - 1;
                 x[cp][tn] = *reinterpret_cast<const f32x4*>(xin + (size_t)(b * P + p) * F + (c0 + cp) * 16 + kq * 4);
             }
-        // ... and so are the pass's per-channel parameters
+        // ... and so are the pass's per-channel parameters (at F = 256 the split-output variant has no registers left for that:
+        // there the parameters are fetched behind the MFMAs, as before)
+        constexpr bool PARAMS_EARLY = !(X2O && F > 128);
         f32x4 vbs[CP], vbt[CP], vps[CP], vpt[CP], vs2[CP], vt2[CP];
+        auto load_params = [&]() {
 #pragma unroll
         for (int cp = 0; cp < CP; ++cp) {
             const int c = (c0 + cp) * 16 + kq * 4;
@@ -1360,6 +1363,8 @@ __global__ __launch_bounds__(256, TG_ATT_OCC) void k_attention_mfma(const float*
             if (ps) { vps[cp] = *reinterpret_cast<const f32x4*>(ps + c); vpt[cp] = *reinterpret_cast<const f32x4*>(pt + c); }
             if (out2) { vs2[cp] = *reinterpret_cast<const f32x4*>(s2 + c); vt2[cp] = *reinterpret_cast<const f32x4*>(t2 + c); }
         }
+        };
+        if constexpr (PARAMS_EARLY) load_params();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk)
@@ -1369,6 +1374,7 @@ __global__ __launch_bounds__(256, TG_ATT_OCC) void k_attention_mfma(const float*
                 for (int tn = 0; tn < NT; ++tn)
                     acc[cp][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[pass & 1][kk][cp], e[kk >> 2][tn][kk & 3], acc[cp][tn], 0, 0, 0);
         // D tile: row = channel (c0+cp)*16 + kq*4 + r, column = position tn*16 + j
+        if constexpr (!PARAMS_EARLY) load_params();
 #pragma unroll
         for (int cp = 0; cp < CP; ++cp) {
             const int c = (c0 + cp) * 16 + kq * 4;

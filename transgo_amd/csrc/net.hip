@@ -352,6 +352,9 @@ __device__ __forceinline__ int swz64(int row) { return ((row >> 2) & 1) << 1; }
 #ifndef TG_H2_XCD
 #define TG_H2_XCD 0        // experiment switch: XCD-contiguous row-tile order in k_conv3x3_h2
 #endif
+#ifndef TG_X2_3P
+#define TG_X2_3P 1         // split precision: three partial products per stage pair (0: all four)
+#endif
 #ifndef TG_SG_PERSIST128
 #define TG_SG_PERSIST128 0
 #endif
@@ -809,9 +812,53 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
 
 #pragma unroll 1                                                         // unrolled, hipcc keeps 4 pairs of address state live and spills
         for (int pp = 0; pp < NPAIR; ++pp) {
+          const int g0 = 2 * pp;
+          if constexpr (X2 && TG_X2_3P) {
+            // THREE partial products per pair of stages instead of four: w_lo * a_lo (2^-22 of a product, below the f32 rounding of the
+            // sum) is dropped.  Steps of a pair (s0, s1 = its two stages, same or neighbouring slice, both tiles in the ring):
+            //   CT steps  [w_hi(s0) | w_hi(s0)] x [a_hi(s0) | a_lo(s0)]      (as before)
+            //   CT steps  [w_hi(s1) | w_hi(s1)] x [a_hi(s1) | a_lo(s1)]      (as before)
+            //   CT steps  [w_lo(s0) | w_lo(s1)] x [a_hi(s0) | a_hi(s1)]      -- both lo-weight products in ONE K = 32 step: the B operand is
+            //             made in place from the two stages' fragments by v_permlane32_swap (the hi halves live in lanes 0-31), the A
+            //             operand takes its lo chunks from tile s0 in lanes 0-31 and from tile s1 in lanes 32-63.
+            // 3/4 of the MFMA steps and of the weight-fragment reads; b_cur holds s0's fragments, b_next s1's, and after the swap
+            // b_next is free for the next pair's first stage.
+            constexpr int NU = 3 * CT, DA = 4;
+            const _Float16* const wmix = ws[(g0 + (kq >> 1)) % NSLOT] + aoff_lo;
+            auto a_addr = [&](int un) -> const _Float16* {
+                const int kind = un / CT, ct = un % CT;
+                return kind == 2 ? wmix + ct * 16 * KC : ws[(g0 + kind) % NSLOT] + ct * 16 * KC + aoff;
+            };
+            f32x4 a[DA];
+#pragma unroll
+            for (int u = 0; u < DA - 1; ++u) a[u] = *reinterpret_cast<const f32x4*>(a_addr(u));
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                if (u + DA - 1 < NU) a[(u + DA - 1) % DA] = *reinterpret_cast<const f32x4*>(a_addr(u + DA - 1));
+                if (u == CT / 2) read_b(b_next, g0 + 1);                                  // s1's fragments, needed from step CT on
+                if (u == 2 * CT) {                                                        // b_cur <- [a_hi(s0) | a_hi(s1)]
+#pragma unroll
+                    for (int t = 0; t < NPT; ++t)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float fc = b_cur[t][e], fn = b_next[t][e];     // (scalar copies: a bit_cast of a vector ELEMENT miscompiles)
+                            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(fc), __float_as_uint(fn), false, false);
+                            b_cur[t][e] = __uint_as_float(r[0]);
+                        }
+                }
+                if (u == 2 * CT + CT / 2 && g0 + 2 < NST) read_b(b_next, g0 + 2);         // the next pair's first stage (its slab is visible)
+                const int ct = u % CT;
+#pragma unroll
+                for (int t = 0; t < NPT; ++t)
+                    acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a[u % DA]), __builtin_bit_cast(h8, u / CT == 1 ? b_next[t] : b_cur[t]),
+                                                                        acc[ct][t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int t = 0; t < NPT; ++t) b_cur[t] = b_next[t];
+          } else {
             constexpr int SPS = X2 ? 2 * CT : CT;                        // MFMA steps per stage (X2: hi and lo fragment of every cout tile)
             constexpr int NU = 2 * SPS, DA = 4;
-            const int g0 = 2 * pp;
             // A fragments run DA-1 steps ahead of their MFMAs (a step = 4 MFMAs = 64 cycles; an LDS read under load takes longer)
             auto a_addr = [&](int un) -> const _Float16* {
                 const int st = un / SPS, w = un % SPS;
@@ -836,6 +883,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
                 }
                 __builtin_amdgcn_sched_barrier(0);                      // keep each step's reads where they were issued (hipcc sinks them to their use)
             }
+          }
             // every DMA of this wave was issued at least one pair ago: wait for all of them, then meet the other waves.  After the
             // barrier the two slots of this pair are free, and so is the slab buffer of slice sl-1 once stage 9*sl-1 is behind us.
             TG_VMCNT(0);
@@ -852,13 +900,21 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
         int mrow[NPT];
 #pragma unroll
         for (int t = 0; t < NPT; ++t) mrow[t] = m0 + (wave * NPT + t) * 16 + j;
+        if constexpr (X2) {
+            // opaque here: computed before the stage loop, the epilogue's 64-bit addresses are spilled across it and reloaded BEHIND the
+            // epilogue's stores (scratch reloads queue on the same in-order counter)
+            static_assert(NPT == 4, "four row tiles per wave");
+            asm volatile("" : "+v"(mrow[0]), "+v"(mrow[1]), "+v"(mrow[2]), "+v"(mrow[3]));
+        }
+        int Me = M, kqe = kq;                                             // likewise the row count and the lane's chunk index the plane offsets are made of
+        if constexpr (X2) { asm volatile("" : "+s"(Me)); asm volatile("" : "+v"(kqe)); }
         // every wave is past the last barrier: ring and slab buffers are free, so the next tile's first loads go out before this
         // tile's results do and land while the epilogue runs
         int nb = bid + gridDim.x;
         while (nb < nblk && tile_m0(nb) >= M) nb += gridDim.x;
         const bool have_next = nb < nblk;
         if (have_next) { bid = nb; m0 = tile_m0(nb); prologue(); }
-        conv_epilogue_h8<F, CT, NPT, (EPI == 1 ? 2 : EPI), R16, X2>(acc, mrow, M, co0, kq, out32, out16, par, NCO, wsc);   // EPI 4: the stem
+        conv_epilogue_h8<F, CT, NPT, (EPI == 1 ? 2 : EPI), R16, X2>(acc, mrow, Me, co0, kqe, out32, out16, par, NCO, wsc);   // EPI 4: the stem
         if (!have_next) break;
     }
 }

@@ -137,8 +137,8 @@ def tree_roofline(S, C, sims, evals, depth_sum, children_scored, tree_ms, waves)
 def kernel_name(S, filters, dtype):
     """The F->F 3x3 conv kernel net.hip dispatches for this configuration (transgo_amd/csrc/net.hip: forward_t)."""
     if dtype == "f32x3":
-        return (f"k_conv3x3_h2<{S},{2 * filters},{filters},X2> (split precision: operands as fp16 hi + lo, the four partial products "
-                "on v_mfma_f32_16x16x32_f16, f32 accumulate, f32 residual stream; LDS-DMA fed)")
+        return (f"k_conv3x3_h2<{S},{2 * filters},{filters},X2> (split precision: operands as fp16 hi + lo, three partial products "
+                "(hi*hi, hi*lo, lo*hi) on v_mfma_f32_16x16x32_f16, f32 accumulate, f32 residual stream; LDS-DMA fed)")
     if dtype != "f32":
         return (f"k_conv3x3_h2<{S},{filters}> (fp16 operands, v_mfma_f32_16x16x32_f16, f32 accumulate, LDS-DMA fed"
                 + (", fp16 residual stream)" if dtype == "f16r" else ")"))
@@ -175,7 +175,7 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", choices=["f32", "f16", "f16r", "f32x3"], default="f32",
                     help="network arithmetic: f32 (BASELINE metric, exact-fp32 MFMA), f16 / f16r = fp16 storage + f32 accumulate "
                          "(configs[4]; f16r: fp16 residual stream too), f32x3 = opt-in split-precision convs (operands as fp16 hi + lo, "
-                         "their four partial products on the fp16 MFMA, f32 accumulate; ~1e-6 of f32)")
+                         "three of their four partial products on the fp16 MFMA, f32 accumulate; ~1e-7 of f32)")
     ap.add_argument("--network", choices=["tower", "transgo"], default="tower",
                     help="tower = BASELINE.json's N-block x F-filter net; transgo = the reference's shipped MainNetwork (model.py:41-114)")
     ap.add_argument("--stagger", type=int, default=-1,
@@ -465,7 +465,7 @@ def main(argv=None):
         value = sims_all / dt
         conv_tflops = (fl.value / (ms.value * 1e-3)) / 1e12 if ms.value > 0 else 0.0
         fpl = flops_per_leaf(S, 10, a.filters, a.blocks) if a.network == "tower" else None
-        peak = {"f32": PEAK_F32_MATRIX_TFLOPS, "f32x3": PEAK_F16_MATRIX_TFLOPS / 4.0}.get(a.dtype, PEAK_F16_MATRIX_TFLOPS)
+        peak = {"f32": PEAK_F32_MATRIX_TFLOPS, "f32x3": PEAK_F16_MATRIX_TFLOPS / 3.0}.get(a.dtype, PEAK_F16_MATRIX_TFLOPS)
         tree = tree_roofline(S, 10, sims, evals, depth, cs1.value - cs0.value, cms.value + ams.value, nw.value)
         if tree:
             tree["share_of_step"] = round((cms.value + ams.value) / (dt * 1e3), 4)
@@ -496,8 +496,9 @@ def main(argv=None):
                          "unit": "TFLOP/s", "frac": round(conv_tflops / peak, 4), "traffic": traffic,
                          "traffic_note": (f"HBM bytes per full-batch launch, FETCH_SIZE x2 + WRITE_SIZE (profiles/{os.path.basename(tfile)})"
                                           if traffic is not None else "PMC traffic was collected for the 9x9 / 128-filter / 4096-board workload only"),
-                         "peak_note": ("dense fp16 MFMA peak / 4: every F->F conv runs its four partial products (w_hi + w_lo)(a_hi + a_lo) "
-                                       "on the fp16 MFMA; achieved counts the conv's 2*9*F*F FLOP per row once") if a.dtype == "f32x3" else None,
+                         "peak_note": ("dense fp16 MFMA peak / 3: every F->F conv runs three partial products (w_hi a_hi, w_hi a_lo, w_lo a_hi; "
+                                       "w_lo a_lo, 2^-22 of a product, is dropped) on the fp16 MFMA; achieved counts the conv's 2*9*F*F FLOP "
+                                       "per row once") if a.dtype == "f32x3" else None,
                          "kernel": kernel_name(S, a.filters, a.dtype),
                          "launches": int(nl.value), "launches_not_timed": int(nskip.value),
                          "avg_launch_ms": round(ms.value / max(1, nl.value), 4),

@@ -56,8 +56,8 @@ typedef struct tg_config {
     int32_t device;             /* HIP device ordinal */
     int32_t net_precision;      /* 0 = f32 network (default); 1 = fp16 weights/activations, f32 accumulate (BASELINE config 5), f32
                                    residual stream; 2 = as 1 with the residual stream stored in fp16 too (a quarter less HBM traffic);
-                                   3 = split precision, opt-in: every conv operand as fp16 hi + lo, all four partial products on the
-                                   fp16 matrix cores, f32 accumulate and residual stream (fp32-level accuracy at 2.2-2.7x the
+                                   3 = split precision, opt-in: every conv operand as fp16 hi + lo, three of the four partial products (lo*lo dropped) on the
+                                   fp16 matrix cores, f32 accumulate and residual stream (fp32-level accuracy at 2.4-3.1x the
                                    simulations/s).  1 and 2 take attention-free towers of 128 / 256 filters; 3 also takes
                                    attention layers at 9x9 (the reference's MainNetwork), anything else is refused by tg_net_load */
     int32_t record_games;       /* 1 (default): every game's move record -- env.encode(root) bit-packed, raw visit counts, side to

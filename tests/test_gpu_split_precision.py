@@ -1,5 +1,5 @@
 """Opt-in split-precision network ("f32x3", net_precision 3): every conv operand of the tower is carried as fp16
-hi + lo, the four partial products (w_hi + w_lo)(a_hi + a_lo) run on the fp16 matrix cores with f32 accumulation, the residual
+hi + lo, three of the four partial products of (w_hi + w_lo)(a_hi + a_lo) (lo*lo is dropped) run on the fp16 matrix cores with f32 accumulation, the residual
 stream, the narrow head conv and the dense heads stay f32.  ~22 significand bits per operand: the outputs must sit within 1e-5 of
 the fp32 torch tower (north_star allows 1e-3), and searches driven by it must agree with the oracle driving the torch network about
 as well as the exact-f32 path does.  The default path is untouched (tests/test_gpu_net.py)."""

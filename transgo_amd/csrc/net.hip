@@ -43,7 +43,7 @@ struct Net {
     float* bufAct = nullptr;                       // pre-activated input of the next conv (DMA path)
     int* tile_ctr = nullptr;                       // [2*NB] tile counters of the persistent conv launches (zeroed per forward)
     int prec = 0;                                  // cfg.net_precision: 0 = f32, 1 = fp16 storage + f32 accumulate (k_conv3x3_h2), 2 = 1 + fp16 residual stream,
-                                                   // 3 = split precision ("f32x3"): every operand as fp16 hi + lo, all four products on the fp16 MFMA, f32 accumulate
+                                                   // 3 = split precision ("f32x3"): every operand as fp16 hi + lo, three of the four products on the fp16 MFMA, f32 accumulate
     const float* head_g = nullptr; const float* head_ag = nullptr;   // [64][F] head conv weights for k_head_gemm (tap*6 + cout rows)
     float* wsc = nullptr;                          // prec 3: [2*NB + 1] power-of-two factor 2^-s each conv's weights were scaled by before splitting (stem last)
     _Float16* stem_h = nullptr; _Float16* head_h = nullptr; _Float16* x0h = nullptr;   // fp16 path: stem [2*9][F][32] (16 planes padded to 64), head [F/32*9][16][32], input [rows][P][64]
@@ -663,6 +663,8 @@ __device__ __forceinline__ void conv_epilogue_h8(f32x4 (&acc)[CT][NPT], const in
 // accumulation from ONE read of the activations and two reads of the SAME weight tile (lane (j, kq) takes 16-B chunk kq & 1 of
 // row j for the hi fragment, 2 + (kq & 1) for the lo one -- no duplicate storage, the swizzle and its conflict-freedom carry
 // over).  4 x the MFMA work of the plain fp16 conv at ~22 significand bits per operand, against 16 x for the exact-f32 MFMA.
+// With TG_X2_3P (default) only THREE of the four products are formed -- w_lo*a_lo is dropped and the two lo-weight products of a
+// pair of stages share one K = 32 step (see the stage loop): 3 x the MFMA work of the plain fp16 conv.
 template <int S, int CIN, int F, int EPI, bool R16 = false, bool X2 = false>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restrict__ in, float* __restrict__ out32,
                                                        _Float16* __restrict__ out16, const float* __restrict__ res,
@@ -1992,7 +1994,7 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
     if constexpr (F == 128 || F == 256) {
         if (n->prec == 3) {
             // Split-precision chain ("f32x3"): the f32 tower's arithmetic with every conv operand carried as fp16 hi + lo and all
-            // four partial products on the fp16 matrix cores (k_conv3x3_h2<..., X2>): stem and tower convs; the residual stream
+            // three of the four partial products on the fp16 matrix cores (k_conv3x3_h2<..., X2>): stem and tower convs; the residual stream
             // stays f32 row-major, the narrow head conv and the dense heads are the f32 kernels.  Opt-in: not the default path.
             if ((long long)M * F * 4 >= (1ll << 31)) TG_FAIL(ctx, TG_ERR_ARG, "split-precision path: rows * P * F * 4 bytes must stay below 2 GiB per activation buffer");
             const int grid_h = (M + 255) / 256;

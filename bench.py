@@ -187,7 +187,7 @@ def parse_args(argv=None):
                          "roofline figures are defined on (with K > 1 launches of different groups share the chip, so per-launch "
                          "durations are no longer exclusive and `roofline` says so)")
     ap.add_argument("--arena-slots", type=int, default=0,
-                    help="32-byte tree slots per game and half arena (default: (3*sims + 256) * (header + actions)); the line reports "
+                    help="32-byte tree slots per game and half arena (default: (4*sims + 256) * (header + actions)); the line reports "
                          "the high-water mark and any truncated tree blocks, so a 19x19 run can be sized for more boards per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=0.0,
@@ -347,7 +347,7 @@ def main(argv=None):
     if a.network == "transgo" and not a.arena_slots:
         # the shipped MainNetwork's policies are peaked even at random init: at the default arena 0.5 % of the game-moves lose kept
         # sub-tree blocks at re-rooting (counted in truncated_tree_blocks; DESIGN.md 3 "Sizing") -- twice the default holds them all
-        a.arena_slots = 2 * (3 * a.sims + 256) * ((2 if S == 9 else 4) + S * S + 1)
+        a.arena_slots = 2 * (4 * a.sims + 256) * ((2 if S == 9 else 4) + S * S + 1)
     if a.groups > 1:
         sp = GroupedSelfPlay(cfg, a.games, groups=a.groups, device=gpu, rank=rank, world=world, arena_slots=a.arena_slots)
         parts = sp.parts
@@ -523,7 +523,7 @@ def main(argv=None):
             "extra": {"leaves_per_s": round(evals_all / dt, 1), "mean_depth": round(depth_all / max(1.0, sims_all), 3),
                       "net_tflops_end_to_end": round(evals_all * fpl / dt / 1e12, 2) if fpl else None,
                       "tree_errors": st1["errors"], "arena_high_water_slots": st1["max_slots"],
-                      "arena_slots_per_half": int(eng.ctx.cfg.arena_slots) or (3 * a.sims + 256) * ((2 if S == 9 else 4) + S * S + 1),
+                      "arena_slots_per_half": int(eng.ctx.cfg.arena_slots) or (4 * a.sims + 256) * ((2 if S == 9 else 4) + S * S + 1),
                       "truncated_tree_blocks": st1["truncated_blocks"],
                       "step_phases_ms": dict({k: round(v / a.steps * 1e3, 2) for k, v in phase_s.items()},
                                              begin_move_inside_search=round(begin_move_s / a.steps * 1e3, 2)),

@@ -713,7 +713,7 @@ int tg_engine_create(tg_ctx* ctx) {
     sc.c1f = (float)cfg.c_puct1; sc.c2f = (float)cfg.c_puct2; sc.A = A;
     sc.maxd = ((cfg.max_step + 2 + 63) / 64) * 64;
     if (sc.maxd > kMaxPath) TG_FAIL(ctx, TG_ERR_ARG, "max_step too large for the path buffer (at most 510)");
-    long long slots = cfg.arena_slots > 0 ? cfg.arena_slots : (3LL * cfg.num_simulation + 256) * (HS + A);
+    long long slots = cfg.arena_slots > 0 ? cfg.arena_slots : (4LL * cfg.num_simulation + 256) * (HS + A);   // 3x truncated kept sub-trees in 0.2 % of the game-moves of full-length games
     if (slots < 4LL * (HS + A) || slots > 0x3fffffffLL) TG_FAIL(ctx, TG_ERR_ARG, "arena_slots out of range");
     sc.arena_slots = (int)slots;
     // room a full search can need: one block per evaluated leaf, at most num_simulation + R of them per move

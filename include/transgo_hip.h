@@ -50,7 +50,7 @@ typedef struct tg_config {
     int32_t wu_loss;            /* configure.py:32 (2) */
     double c_puct1;             /* configure.py:26 (3) */
     double c_puct2;             /* configure.py:27 (0.05) */
-    int32_t arena_slots;        /* 32-byte tree slots per game per half arena; 0 = sized from num_simulation */
+    int32_t arena_slots;        /* 32-byte tree slots per game per half arena; 0 = (4*num_simulation + 256) blocks of the largest size */
     int32_t net_blocks;         /* residual blocks of the tower (BASELINE.json "N-block x F-filter") */
     int32_t net_filters;        /* channels F (multiple of 32) */
     int32_t device;             /* HIP device ordinal */

@@ -2,9 +2,12 @@
 """bench.py -- MCTS simulations/sec of the batched self-play hot path on N MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-        N > 1 and no RANK/WORLD_SIZE in the environment: this process becomes a GPU-free LAUNCHER (as the reference's driver
+        no RANK/WORLD_SIZE in the environment (any N, 1 included): this process is a GPU-free LAUNCHER (as the reference's driver
         spawns its own workers, transgo.py:92-107): it times the CPU baseline, starts N fresh child processes (one rank per GPU,
-        RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), forwards rank 0's JSON line and exits non-zero if any rank fails.
+        RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), takes rank 0's JSON line and exits non-zero if any rank fails.  At N = 1
+        it then runs the SECONDARY legs -- the same workload under the opt-in split-precision network (`--dtype f32x3`) and under
+        the reference's shipped MainNetwork in exact f32 (`--network transgo`) -- each in a fresh child of its own, one after the
+        other, and prints ONE line: the exact-f32 tower as metric / value / dtype / config, the legs under "secondary".
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
         (ranks started by somebody else: rank 0 times the CPU baseline before it touches the GPU, the others wait in
         init_process_group)
@@ -194,6 +197,15 @@ def parse_args(argv=None):
                     help="window of each CPU-baseline leg (default: 60 s at N = 1 as BASELINE.md 4 says, 30 s at N > 1)")
     ap.add_argument("--cpu-json", default="", help="(set by the launcher) file holding the CPU-baseline legs the launcher timed")
     ap.add_argument("--launch-timeout", type=float, default=3000.0, help="launcher: seconds before the ranks are given up on")
+    ap.add_argument("--no-launcher", action="store_true",
+                    help="N = 1 only: be rank 0 of a world of one in THIS process (no children, no secondary legs) -- what a profiler "
+                         "needs (`rocprofv3 ... -- python3 bench.py --no-launcher --no-cpu-baseline`): its preloaded library has "
+                         "initialised the GPU before Python starts, and such a process must not start GPU children")
+    ap.add_argument("--secondary", choices=["auto", "none"], default="auto",
+                    help="auto: after the headline leg of the default family (N = 1, tower, f32, one group) the launcher times the "
+                         "f32x3 tower and the f32 MainNetwork on the same workload in fresh child processes and reports them under "
+                         "\"secondary\" (never as `value`)")
+    ap.add_argument("--secondary-timeout", type=float, default=240.0, help="launcher: seconds one secondary leg may take")
     return ap.parse_args(argv)
 
 
@@ -216,43 +228,33 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def launcher(a, argv):
-    """`python bench.py --gpus N` with N > 1 and no rank environment: the GPU-free parent (nothing here imports torch or touches
-    HIP).  CPU legs first, then N fresh children -- this same file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set -- whose
-    rank 0 prints the JSON line with the CPU legs merged in.  Any failing rank, or the join timeout, ends the others (exact
-    PIDs) and the launcher exits non-zero."""
+def _spawn_ranks(argv, n, tmp, tag, timeout_s):
+    """Start n fresh children of this file (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), wait for them, end every rank (exact
+    PIDs) as soon as one fails or the timeout passes.  Returns (rc, rank 0's stdout, why)."""
     import subprocess
-    import tempfile
-    cpu, cpu_c1 = cpu_legs(a)
-    tmp = tempfile.mkdtemp(prefix="transgo_bench_")
-    cpu_json = os.path.join(tmp, "cpu.json")
-    with open(cpu_json, "w") as f:
-        json.dump({"cpu_baseline": cpu, "cpu_baseline_c1": cpu_c1}, f)
     port = int(os.environ.get("MASTER_PORT", 0)) or _free_port()
-    args = [x for x in argv] + ["--no-cpu-baseline", "--cpu-json", cpu_json]
     procs, outs = [], []
-    for r in range(a.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(port),
                    TRANSGO_BENCH_LAUNCHER="bench.py")
-        out = open(os.path.join(tmp, f"rank{r}.out"), "w+")
+        out = open(os.path.join(tmp, f"{tag}_rank{r}.out"), "w+")
         outs.append(out)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + args, env=env, stdout=out, stderr=None))
-    deadline = time.time() + a.launch_timeout
-    rc = 0
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out, stderr=None))
+    deadline = time.time() + timeout_s
+    rc, why = 0, ""
     try:
         while True:
             codes = [p.poll() for p in procs]
             bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
             if bad:
                 rc = bad[0][1] if bad[0][1] > 0 else 1
-                print(f"bench.py launcher: rank {bad[0][0]} exited with {bad[0][1]}; stopping the other ranks", file=sys.stderr)
+                why = f"rank {bad[0][0]} exited with {bad[0][1]}; stopping the other ranks"
                 break
             if all(c == 0 for c in codes):
                 break
             if time.time() > deadline:
-                rc = 124
-                print(f"bench.py launcher: ranks still running after {a.launch_timeout:.0f} s; giving up", file=sys.stderr)
+                rc, why = 124, f"ranks still running after {timeout_s:.0f} s; giving up"
                 break
             time.sleep(0.2)
     finally:
@@ -264,31 +266,99 @@ def launcher(a, argv):
                 p.wait(20)
             except subprocess.TimeoutExpired:
                 p.kill()
+    txt0 = ""
     for r, out in enumerate(outs):
         out.seek(0)
         txt = out.read()
         out.close()
         if r == 0:
-            sys.stdout.write(txt)
+            txt0 = txt
         elif txt.strip():
             sys.stderr.write(txt)
-    sys.stdout.flush()
-    if rc == 0 and not any(l.startswith("{") for l in txt_lines(os.path.join(tmp, "rank0.out"))):
+    return rc, txt0, why
+
+
+def _result_line(txt):
+    for l in reversed(txt.splitlines()):
+        if l.startswith("{"):
+            try:
+                return json.loads(l)
+            except ValueError:
+                pass
+    return None
+
+
+# What the launcher times after the headline leg at N = 1: the round's opt-in modes where the driver's clock
+# sees them.  (name, arguments replacing the headline's, cap on steps, cap on warm-up)
+SECONDARY_LEGS = (
+    ("f32x3", ["--dtype", "f32x3"], 10, 3),
+    ("mainnetwork_f32", ["--network", "transgo", "--dtype", "f32"], 3, 1),
+)
+
+
+def _secondary_summary(line, wall_s):
+    rf, ex = line.get("roofline") or {}, line.get("extra") or {}
+    return {"value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"], "steps": line["steps"],
+            "warmup": line["warmup"], "dtype": line["dtype"], "games_per_hour": line.get("games_per_hour"),
+            "workload": (line.get("config") or {}).get("workload"),
+            "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "peak_note", "kernel", "launches",
+                                                "launches_not_timed", "avg_launch_ms")},
+            "net_tflops_end_to_end": ex.get("net_tflops_end_to_end"), "leaves_per_s": ex.get("leaves_per_s"),
+            "tree_errors": ex.get("tree_errors"), "fp16_overflows": ex.get("fp16_overflows"),
+            "truncated_tree_blocks": ex.get("truncated_tree_blocks"), "arena_high_water_slots": ex.get("arena_high_water_slots"),
+            "leg_wall_s": round(wall_s, 1)}
+
+
+def launcher(a, argv):
+    """`python bench.py --gpus N` with no rank environment: the GPU-free parent (nothing here imports torch or touches HIP).
+    CPU legs first, then N fresh children -- this same file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set -- whose rank 0
+    writes the JSON line with the CPU legs merged in.  Any failing rank, or the join timeout, ends the others (exact PIDs) and
+    the launcher exits non-zero.  At N = 1 the secondary legs follow, each in its own fresh child (never an exec, never a second
+    network inside a process that already holds one): a leg that fails leaves {"error": ...} under its name and does not take
+    the headline with it."""
+    import tempfile
+    cpu, cpu_c1 = cpu_legs(a)
+    tmp = tempfile.mkdtemp(prefix="transgo_bench_")
+    cpu_json = os.path.join(tmp, "cpu.json")
+    with open(cpu_json, "w") as f:
+        json.dump({"cpu_baseline": cpu, "cpu_baseline_c1": cpu_c1}, f)
+    args = [x for x in argv] + ["--no-cpu-baseline", "--cpu-json", cpu_json]
+    t0 = time.time()
+    rc, txt, why = _spawn_ranks(args, a.gpus, tmp, "main", a.launch_timeout)
+    line = _result_line(txt)
+    if rc != 0:
+        print(f"bench.py launcher: {why}", file=sys.stderr)
+        sys.stdout.write("".join(l + "\n" for l in txt.splitlines() if not l.startswith("{")))
+        return rc
+    if line is None:
         print("bench.py launcher: rank 0 printed no result line", file=sys.stderr)
-        rc = 1
-    return rc
-
-
-def txt_lines(path):
-    with open(path) as f:
-        return f.read().splitlines()
+        return 1
+    line["launcher_wall_s"] = {"cpu_legs_and_headline": round(time.time() - t0, 1)}
+    if a.gpus == 1 and a.secondary == "auto" and (a.dtype, a.network, a.groups) == ("f32", "tower", 1):
+        sec = {}
+        for name, extra, max_steps, max_warm in SECONDARY_LEGS:
+            leg = [x for x in argv] + extra + ["--steps", str(min(a.steps, max_steps)), "--warmup", str(min(a.warmup, max_warm)),
+                                               "--no-cpu-baseline"]
+            t1 = time.time()
+            rc2, txt2, why2 = _spawn_ranks(leg, 1, tmp, name, a.secondary_timeout)
+            l2 = _result_line(txt2)
+            if rc2 == 0 and l2 is not None:
+                sec[name] = _secondary_summary(l2, time.time() - t1)
+            else:
+                sec[name] = {"error": why2 or "no result line", "rc": rc2, "leg_wall_s": round(time.time() - t1, 1)}
+                print(f"bench.py launcher: secondary leg {name} failed ({sec[name]['error']})", file=sys.stderr)
+        line["secondary"] = dict(sec, note="same workload, same launcher, fresh process each, timed after the headline leg; "
+                                           "opt-in modes reported beside the exact-f32 tower, never as `value`")
+        line["launcher_wall_s"]["secondary"] = round(sum(v.get("leg_wall_s", 0) for v in sec.values()), 1)
+    print(json.dumps(line), flush=True)
+    return 0
 
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     a = parse_args(argv)
     have_ranks = "RANK" in os.environ and "WORLD_SIZE" in os.environ
-    if a.gpus > 1 and not have_ranks:
+    if not have_ranks and not (a.no_launcher and a.gpus == 1):
         raise SystemExit(launcher(a, argv))
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -331,12 +401,17 @@ def main(argv=None):
         ranks = {"world": dist.get_world_size(), "backend": dist.get_backend(), "devices": seen,
                  "distinct_gpus": len({(d["device"], d["bus"], d["uuid"]) for d in seen}),
                  "launcher": os.environ.get("TRANSGO_BENCH_LAUNCHER", "external (torch.distributed.run)")}
+        if ranks["backend"] == "nccl" and ranks["distinct_gpus"] < ranks["world"]:
+            # every rank sees the same list and leaves together: a job whose ranks share a card is not the job --gpus names
+            raise SystemExit(f"bench.py: {ranks['world']} RCCL ranks on {ranks['distinct_gpus']} distinct GPU(s) "
+                             f"({[(d['rank'], d['device'], d['bus']) for d in seen]}): refusing to report it as --gpus {a.gpus}")
     else:
-        ranks = {"world": 1, "backend": None, "devices": [me], "distinct_gpus": 1, "launcher": "none"}
+        ranks = {"world": 1, "backend": None, "devices": [me], "distinct_gpus": 1,
+                 "launcher": os.environ.get("TRANSGO_BENCH_LAUNCHER", "none")}
 
     from transgo_amd import model
     from transgo_amd.configure import Config
-    from transgo_amd.distributed import gather_harvest
+    from transgo_amd.distributed import gather_harvest, transport_name
     from transgo_amd.replay_buffer import DeviceReplayMemory
     from transgo_amd.self_play import BatchedSelfPlay, GroupedSelfPlay
 
@@ -452,7 +527,23 @@ def main(argv=None):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    own_dt = dt
     dt = float(t.item()); sims_all, evals_all, depth_all, fin_all, drop_all = [float(x) for x in s.tolist()]
+    # every rank's own clock and count next to the job figure (value = sum of sims / slowest rank's time hides a straggler)
+    mine = {"rank": rank, "device": int(dev.index), "sims": int(sims), "seconds": round(own_dt, 4),
+            "ms_per_step": round(own_dt / a.steps * 1e3, 2), "sims_per_s": round(sims / own_dt, 1),
+            "games_finished": int(sp.games_finished - fin0)}
+    seeds_now = np.concatenate([np.asarray(part.seeds, np.int64) for part in parts])      # the games running in this rank's slots
+    mine["seed_min"], mine["seed_max"] = int(seeds_now.min()), int(seeds_now.max())
+    per_rank, all_seeds = [mine], [seeds_now]
+    if world > 1:
+        per_rank, all_seeds = [None] * world, [None] * world
+        dist.all_gather_object(per_rank, mine)
+        dist.all_gather_object(all_seeds, seeds_now)
+    ranks["per_rank"] = per_rank
+    cat = np.concatenate(all_seeds)
+    ranks["seeds_disjoint"] = bool(len(np.unique(cat)) == len(cat))       # no two running games of the job share an RNG stream
+    ranks["transport"] = transport_name() if world > 1 else "none (one rank: finished games go device -> device into the store)"
 
     if rank == 0:
         # HBM bytes per launch of the dominant kernel come from PMC passes (separate rocprofv3 runs, committed under profiles/);
@@ -522,7 +613,8 @@ def main(argv=None):
                                "replay_entries": info["entries"], "consumer": "DeviceReplayMemory on rank 0 (tg_replay_append_dev)"},
             "extra": {"leaves_per_s": round(evals_all / dt, 1), "mean_depth": round(depth_all / max(1.0, sims_all), 3),
                       "net_tflops_end_to_end": round(evals_all * fpl / dt / 1e12, 2) if fpl else None,
-                      "tree_errors": st1["errors"], "arena_high_water_slots": st1["max_slots"],
+                      "tree_errors": st1["errors"], "fp16_overflows": st1["fp16_overflows"],
+                      "arena_high_water_slots": st1["max_slots"],
                       "arena_slots_per_half": int(eng.ctx.cfg.arena_slots) or (4 * a.sims + 256) * ((2 if S == 9 else 4) + S * S + 1),
                       "truncated_tree_blocks": st1["truncated_blocks"],
                       "step_phases_ms": dict({k: round(v / a.steps * 1e3, 2) for k, v in phase_s.items()},

@@ -211,6 +211,8 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch, const float* blob, size_t n_
  * weight sets; this call copies the blob to pinned memory and uploads + re-stages it into the idle set on a side stream, then
  * returns.  Searches keep running on the live set; the switch happens at a boundary only: the next tg_sp_begin_move (so one
  * move's search, and its recorded pi, never mixes two weight sets) or the next tg_net_predict that finds the upload complete.
+ * tg_sp_eval / tg_sp_collect / tg_sp_absorb never switch: a host that drives those itself and never calls tg_sp_begin_move must
+ * call tg_net_load_poll(ctx, 0, &pending) where it wants a finished refresh to take over.
  * Falls back to the synchronous load when no network of this architecture is loaded yet.  One refresh in flight at a time (a
  * second call first waits for the previous one).  tg_net_load_poll: pending = 1 while a refresh is not adopted yet; wait != 0
  * blocks until it is. */
@@ -223,6 +225,13 @@ int tg_net_load_poll(tg_ctx* ctx, int wait, int* pending);
 /* main_prediction (model.py:17-20) on host buffers: obs f32[n][C][S][S] -> policy f32[n][A] (softmax), value f32[n]
  * (tanh), own f32[n][S*S] (tanh; may be NULL). */
 int tg_net_predict(tg_ctx* ctx, const float* obs, int n_rows, float* policy, float* value, float* own);
+/* Range report.  The reference network is f32 end to end (model.py:79-114) and accepts any trained checkpoint (model.py:23-27);
+ * net_precision 1 / 2 / 3 carry activations as fp16 (3: as fp16 hi + lo) and lose f32's range: beyond +-65504 the fp16 copy is
+ * inf and the layers behind it compute NaN.  Every kernel that rounds to fp16 checks what it rounds; fp16_overflows = sticky
+ * count, since the network was created, of output tiles (convs) / boards (attention) that held such a value (0 = all forward
+ * passes so far stayed in range; always 0 with net_precision 0); a non-zero count also leaves a message in tg_last_error.
+ * weight_absmax = largest |w| of the live weight set's BatchNorm-folded blob (inf / NaN if it holds one).  Either may be NULL. */
+int tg_net_range(tg_ctx* ctx, uint64_t* fp16_overflows, float* weight_absmax);
 /* HIP-event timing of the dominant kernel (3x3 conv F->F) on the launch stream: enable, run, read totals. */
 int tg_prof_enable(tg_ctx* ctx, int on, int max_launches);
 int tg_prof_read(tg_ctx* ctx, double* conv_ms, int64_t* conv_launches, double* conv_flops);

@@ -3,6 +3,8 @@ hi + lo, three of the four partial products of (w_hi + w_lo)(a_hi + a_lo) (lo*lo
 stream, the narrow head conv and the dense heads stay f32.  ~22 significand bits per operand: the outputs must sit within 1e-5 of
 the fp32 torch tower (north_star allows 1e-3), and searches driven by it must agree with the oracle driving the torch network about
 as well as the exact-f32 path does.  The default path is untouched (tests/test_gpu_net.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -171,4 +173,122 @@ def test_split_precision_search_agrees_with_the_oracle():
                 o.advance(a)
         eng.play(acts)
     print(f"f32x3: identical visit-count vectors {same}/{total}")
+    assert same >= 0.85 * total
+
+
+def test_fp16_range_guard_counts_overflows_in_every_fp16_carrying_mode():
+    """VERDICT r3 item 5.  The reference runs f32 end to end (model.py:79-114) and takes any trained checkpoint (model.py:23-27); the
+    modes that carry fp16 lose f32's range.  A tower whose second block's pre-activation BatchNorm scale is multiplied by 1e5 pushes
+    relu(bn1(x)) far beyond 65504: f16 / f16r / f32x3 must raise the sticky counter (tg_net_range), exact f32 must not (and still
+    stays finite); the same weights with the scale left alone leave the counter at 0 in every mode."""
+    from oracle.net import seeded_tower
+    from transgo_amd.model import HipNetwork
+    S, F, NB, n = 9, 128, 2, 40
+    net = seeded_tower(S, 10, F, NB, seed=77)
+    good = {k: np.array(v) for k, v in net.get_weights().items()}
+    bad = dict(good)
+    bad["main_network.res_blocks.1.batchnormlize_1.weight"] = good["main_network.res_blocks.1.batchnormlize_1.weight"] * np.float32(1e5)
+    x = _positions(S, n, 3)
+    for prec in ("f32", "f16", "f16r", "f32x3"):
+        h = HipNetwork(S, 10, F, NB, rows_cap=n, precision=prec)
+        rng = h.set_weights(good)
+        assert rng["finite"] and 0 < rng["weight_absmax"] < 100
+        h.main_prediction(x)
+        r0 = h.net_range()
+        assert r0["fp16_overflows"] == 0 and abs(r0["weight_absmax"] - rng["weight_absmax"]) <= 1e-6 * rng["weight_absmax"]
+        rng = h.set_weights(bad)
+        assert rng["finite"] and rng["weight_absmax"] > 1e4                  # reported when the weights are handed over
+        p, v, o = h.main_prediction(x)
+        r1 = h.net_range()
+        print(f"{prec}: overflow events {r1['fp16_overflows']}, |w|max {r1['weight_absmax']:.3g}")
+        if prec == "f32":
+            assert r1["fp16_overflows"] == 0 and np.isfinite(p).all() and np.isfinite(v).all() and np.isfinite(o).all()
+        else:
+            assert r1["fp16_overflows"] > 0
+            msg = h.ctx.lib.tg_last_error(h.ctx.h).decode()
+            assert "fp16 overflow" in msg and "65504" in msg
+        h.ctx.close()
+
+
+def test_fp16_range_guard_in_the_fused_attention_block():
+    """The same for the shipped MainNetwork under f32x3: an attention block's BatchNorm scale x 1e5 makes k_attention_x3 round values
+    beyond fp16 into the next residual block's split input -- counted; untouched weights are not."""
+    from transgo_amd.model import HipNetwork, random_transgo_weights, transgo_arch
+    n = 24
+    good = random_transgo_weights(9, 10, 128, seed=9)
+    bad = dict(good)
+    bad["main_network.res_conv3.bn.weight"] = good["main_network.res_conv3.bn.weight"] * np.float32(1e5)
+    x = _positions(9, n, 4)
+    h = HipNetwork(9, 10, 128, rows_cap=n, arch=transgo_arch(), precision="f32x3")
+    h.set_weights(good); h.main_prediction(x)
+    assert h.net_range()["fp16_overflows"] == 0
+    h.set_weights(bad); h.main_prediction(x)
+    assert h.net_range()["fp16_overflows"] > 0
+
+
+def _oracle_two_moves(args):
+    """(worker process, CPU only) the oracle driving the fp32 torch tower for one game: raw root visits and move of each ply."""
+    seed, sims, moves, F, NB, wseed = args
+    import torch
+    torch.set_num_threads(1)
+    from oracle.go_oracle import OracleGoEnv
+    from oracle.net import TowerNetwork
+    from oracle.wp_mcts import OracleSearch
+    from transgo_amd import model
+    net = TowerNetwork(9, 10, F, NB).eval()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in model.random_weights(9, 10, F, NB, seed=wseed).items()})
+
+    def ev(obs):
+        with torch.no_grad():
+            p, v, _ = net.main_prediction(torch.from_numpy(obs))
+        return p.numpy(), v.numpy()
+    o = OracleSearch(OracleGoEnv(), ev, np.random.RandomState(int(seed)), num_simulation=sims)
+    out = []
+    for _ in range(moves):
+        a, pi, _, _ = o.search_move()
+        out.append((np.array([o.root.kids[i].n if i in o.root.kids else 0 for i in range(82)]), int(a)))
+        o.advance(a)
+    return out
+
+
+def test_split_precision_at_c2_size_vs_oracle():
+    """BASELINE configs[1] at its own size under the split-precision network -- 4096 boards x 400 simulations x
+    the real 6 x 128 tower in f32x3, two moves: root-visit window, no tree error, no truncated block, no fp16 overflow, and on 32
+    sampled games the visit vectors against the oracle driving the torch f32 tower (a game is followed while it agrees)."""
+    import multiprocessing as mp
+    from transgo_amd import model
+    from transgo_amd.engine import SelfPlayEngine
+    G, sims, moves, F, NB, wseed = 4096, 400, 2, 128, 6, 1234
+    sample = np.random.RandomState(1).choice(G, 32, replace=False)
+    sample[:4] = [0, 1, G - 2, G - 1]
+    seeds = np.arange(G).astype(np.uint32)
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(min(16, len(os.sched_getaffinity(0)))) as pool:
+        fut = pool.map_async(_oracle_two_moves, [(int(seeds[g]), sims, moves, F, NB, wseed) for g in sample])
+        eng = SelfPlayEngine(G, num_simulation=sims, net_blocks=NB, net_filters=F, net_precision="f32x3")
+        model.load_into(eng.ctx, model.random_weights(9, 10, F, NB, seed=wseed), 9, 10, F, NB)
+        eng.reset(seeds)
+        got, n0 = [], np.zeros(G, np.int64)
+        for m in range(moves):
+            eng.search()
+            vis, rn, pl, st, _ = eng.root_info(obs=False)
+            assert (rn >= n0 + sims).all() and (rn < n0 + sims + 4).all(), m
+            acts, _ = eng.choose_moves(vis, st)
+            got.append((vis[sample].copy(), acts[sample].copy()))
+            eng.play(acts)
+            n0 = np.array([vis[g, acts[g]] for g in range(G)], np.int64)
+        s = eng.stats()
+        assert s["errors"] == 0 and s["truncated_blocks"] == 0 and s["fp16_overflows"] == 0 and s["sims"] >= G * sims * moves
+        eng.close()
+        want = fut.get(timeout=600)
+    same = total = 0
+    for k in range(len(sample)):
+        for m in range(moves):
+            total += 1
+            ok = bool((want[k][m][0] == got[m][0][k]).all() and want[k][m][1] == got[m][1][k])
+            same += int(ok)
+            if not ok:
+                total += moves - 1 - m                       # the rest of a diverged game counts as different
+                break
+    print(f"f32x3 at C2 size: identical visit-count vectors {same}/{total} on {len(sample)} sampled games")
     assert same >= 0.85 * total

@@ -124,7 +124,7 @@ def _gather_worker(rank, world, port, q):
     out = [x for hb in got for x in _summary(hb.records())]
     out1 = [x for hb in only1 for x in _summary(hb.records())]
     nbytes = [hb.nbytes for hb in got]
-    os.environ["TRANSGO_GATHER"] = "allgather"             # the fallback transport delivers the same batches
+    os.environ["TRANSGO_GATHER"] = "p2p"                   # the opt-in exact-length send/recv delivers the same batches
     alt = [x for hb in gather_harvest(h, 9, 10, dst=0) for x in _summary(hb.records())]
     os.environ.pop("TRANSGO_GATHER")
     assert alt == out
@@ -147,6 +147,51 @@ def test_gather_two_ranks_gloo():
     assert o10 == mine1
     assert nb0 == [my0, my1] and my1 > my0                # every payload travels at its own length, not padded to the largest
     assert b0 == b1 == list(np.arange(10, dtype=np.float32))
+
+
+def _gather8_worker(rank, world, port, q):
+    """What one rank of an 8-rank job does per move, over gloo on the CPU: control word, size exchange, payloads (both transports),
+    weight broadcast -- rank 3 and rank 6 finish nothing, the others a ragged number of games."""
+    import torch.distributed as dist
+    from transgo_amd import distributed, records
+    distributed.init_process_group("gloo", rank, world, timeout_s=120.0, init_method=f"tcp://127.0.0.1:{port}")
+    rng = np.random.RandomState(50 + rank)
+    recs = [] if rank in (3, 6) else _fake_games(rng, [2 + (rank + k) % 4 for k in range(1 + rank % 3)], seed0=1000 * rank)
+    h = records.from_records(recs, 9, 10) if recs else None
+    ctl = distributed.control_exchange([rank == 0, 7 if rank == 0 else -1], src=0)
+    res = {}
+    for tr in ("allgather", "p2p"):
+        os.environ["TRANSGO_GATHER"] = tr
+        got, live = distributed.gather_harvest(h, 9, 10, dst=0, live=10 + rank)
+        res[tr] = ([x for hb in got for x in _summary(hb.records())], live, [hb.nbytes for hb in got])
+    os.environ.pop("TRANSGO_GATHER")
+    assert distributed.transport_name().startswith("all_gather")            # the default when nothing is set
+    blob = distributed.broadcast_weights(np.arange(64, dtype=np.float32) if rank == 0 else None, src=0, n_floats=64)
+    q.put((rank, ctl, res, _summary(recs), h.nbytes if h else 0, float(np.asarray(blob).sum())))
+    dist.destroy_process_group()
+
+
+def test_gather_eight_ranks_gloo_both_transports():
+    """BASELINE configs[2]/[4] are world 8: the per-move exchange with eight ranks (two of them with nothing to send), the padded
+    all_gather (default) and the exact-length send/recv deliver the same batches in rank order; only rank 0 receives."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 8
+    ps = [ctx.Process(target=_gather8_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    [p.join(60) for p in ps]
+    assert [p.exitcode for p in ps] == [0] * world
+    want = [x for r in res for x in r[3]]
+    sizes = [r[4] for r in res if r[4]]
+    for rank, ctl, got, _, _, bsum in res:
+        assert ctl == [1, 7] and bsum == float(np.arange(64).sum())
+        for tr in ("allgather", "p2p"):
+            out, live, nbytes = got[tr]
+            assert live == sum(10 + r for r in range(world))
+            assert (out == want and nbytes == sizes) if rank == 0 else (out == [] and nbytes == [])
 
 
 def test_harvest_batch_equals_per_game_targets(tmp_path):

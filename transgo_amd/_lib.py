@@ -74,6 +74,7 @@ SIGNATURES = {
     "tg_net_load_async_dev": (ctypes.c_int, [_vp, ctypes.c_char_p, _vp, ctypes.c_size_t]),
     "tg_net_load_poll": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "tg_net_predict": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
+    "tg_net_range": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_float)]),
     "tg_prof_enable": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "tg_prof_read": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]),
     "tg_prof_skipped": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),

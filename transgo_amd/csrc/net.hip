@@ -58,6 +58,9 @@ struct Net {
     float* hc = nullptr;   // [rows][P][16] head conv output
     float* own = nullptr;  // [rows][P]
     int rows_cap = 0;
+    // range guard: [0] sticky count of epilogue tiles (conv) / boards (attention) that rounded a value beyond +-65504 to fp16 since
+    // the network was created (fp16-carrying precisions only); [1 + k] bit pattern of max |w| over weight set k's BN-folded blob
+    unsigned* range = nullptr;
     // Two complete weight sets (f2, "double-buffered so search never stalls"): the forward pass reads set `active` (the pointer
     // fields above are bound to it); a refresh fills the other one -- tg_net_load_async on a side stream while searches keep
     // running -- and the next forward that finds it complete rebinds.  `swapped` orders a later refill of the retired set behind
@@ -565,7 +568,9 @@ __device__ __forceinline__ int x2_index(int c) { return ((c >> 4) << 5) + (c & 1
 template <int F, int CT, int NPT, int EPI, bool R16, bool X2 = false>
 __device__ __forceinline__ void conv_epilogue_h8(f32x4 (&acc)[CT][NPT], const int (&mrow)[NPT], int M, int co_base, int kq,
                                                  float* __restrict__ out32, _Float16* __restrict__ out16, const float* par, int pstride,
-                                                 float wsc = 1.f) {
+                                                 float wsc, float& amax) {
+    // amax: largest |value| this lane rounded to fp16 (range guard: above 65504 the fp16 copy is inf and the next layer computes
+    // NaN; the caller raises the network's sticky overflow counter, tg_net_range)
     static_assert(CT % 2 == 0, "tile pairs");
     static_assert(!(X2 && R16), "split precision keeps the f32 residual stream");
 #pragma unroll
@@ -583,6 +588,8 @@ __device__ __forceinline__ void conv_epilogue_h8(f32x4 (&acc)[CT][NPT], const in
                     h8 hi, lo;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { const float x = w[e >> 2][e & 3]; hi[e] = (_Float16)x; lo[e] = (_Float16)(x - (float)hi[e]); }
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(w[e >> 2][e & 3]), __builtin_fabsf(w[e >> 2][(e & 3) + 1])));
                     const int c2 = x2_index(col);
                     *reinterpret_cast<h8*>(out16 + h16_index(mrow[t], c2, M)) = hi;
                     *reinterpret_cast<h8*>(out16 + h16_index(mrow[t], c2 + 16, M)) = lo;
@@ -613,7 +620,7 @@ __device__ __forceinline__ void conv_epilogue_h8(f32x4 (&acc)[CT][NPT], const in
             }
             if (EPI == 0) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float w = v[e >> 2][e & 3]; o[e] = (_Float16)(w > 0.f ? w : 0.f); }
+                for (int e = 0; e < 8; ++e) { const float w = v[e >> 2][e & 3]; o[e] = (_Float16)(w > 0.f ? w : 0.f); amax = __builtin_fmaxf(amax, w); }
                 *reinterpret_cast<h8*>(out16 + h16_index(mrow[t], col, M)) = o;
             } else {
                 if (EPI == 4) {
@@ -625,7 +632,7 @@ __device__ __forceinline__ void conv_epilogue_h8(f32x4 (&acc)[CT][NPT], const in
                 if (out32) {                                             // null: the last block (only its activation feeds the head)
                     if (R16) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e >> 2][e & 3];
+                        for (int e = 0; e < 8; ++e) { o[e] = (_Float16)v[e >> 2][e & 3]; amax = __builtin_fmaxf(amax, __builtin_fabsf(v[e >> 2][e & 3])); }
                         *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(out32) + h16_index(mrow[t], col, M)) = o;
                     } else {
 #pragma unroll
@@ -638,7 +645,7 @@ __device__ __forceinline__ void conv_epilogue_h8(f32x4 (&acc)[CT][NPT], const in
                         const f32x4 sc = *reinterpret_cast<const f32x4*>(par + pstride + lc + 4 * h);
                         const f32x4 sh = *reinterpret_cast<const f32x4*>(par + 2 * pstride + lc + 4 * h);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { const float w = v[h][e] * sc[e] + sh[e]; o[4 * h + e] = (_Float16)(w > 0.f ? w : 0.f); }
+                        for (int e = 0; e < 4; ++e) { const float w = v[h][e] * sc[e] + sh[e]; o[4 * h + e] = (_Float16)(w > 0.f ? w : 0.f); amax = __builtin_fmaxf(amax, w); }
                     }
                     *reinterpret_cast<h8*>(out16 + h16_index(mrow[t], col, M)) = o;
                 }
@@ -670,7 +677,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
                                                        _Float16* __restrict__ out16, const float* __restrict__ res,
                                                        const _Float16* __restrict__ Ws, const float* __restrict__ bias,
                                                        const float* __restrict__ s2, const float* __restrict__ t2, int M, int nblk,
-                                                       const float* __restrict__ wsc_p = nullptr) {
+                                                       const float* __restrict__ wsc_p, unsigned* __restrict__ ovf) {
     constexpr int P = S * S, HALO = S + 1, KC = 32, NW = 4, NPT = 4, TM = 64 * NW, NCO = 128, CT = NCO / 16, COS = F / NCO;
     constexpr int NCHK = KC / 8, RPP = 64 / NCHK;                       // 4 chunks per 64-B row, 16 rows per 1-KB DMA piece
     constexpr int NSL = CIN / KC, NST = NSL * 9, NPAIR = NST / 2, NSLOT = 4;        // CIN input channels (row stride), F output channels
@@ -916,7 +923,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_h2(const _Float16* __restric
         while (nb < nblk && tile_m0(nb) >= M) nb += gridDim.x;
         const bool have_next = nb < nblk;
         if (have_next) { bid = nb; m0 = tile_m0(nb); prologue(); }
-        conv_epilogue_h8<F, CT, NPT, (EPI == 1 ? 2 : EPI), R16, X2>(acc, mrow, Me, co0, kqe, out32, out16, par, NCO, wsc);   // EPI 4: the stem
+        float amax = 0.f;
+        conv_epilogue_h8<F, CT, NPT, (EPI == 1 ? 2 : EPI), R16, X2>(acc, mrow, Me, co0, kqe, out32, out16, par, NCO, wsc, amax);   // EPI 4: the stem
+        // range guard: one compare + ballot per tile and wave, an atomic only when a value left the fp16 range (sticky counter)
+        if (__builtin_amdgcn_ballot_w64(!(amax <= 65504.f)) != 0 && lane == 0) atomicAdd(ovf, 1u);
         if (!have_next) break;
     }
 }
@@ -1311,9 +1321,10 @@ __global__ __launch_bounds__(256, TG_ATT_OCC) void k_attention_mfma(const float*
                                                         const float* __restrict__ gamma, const float* __restrict__ bs,
                                                         const float* __restrict__ bt, const float* __restrict__ ps,
                                                         const float* __restrict__ pt, const float* __restrict__ s2,
-                                                        const float* __restrict__ t2, int rows) {
+                                                        const float* __restrict__ t2, int rows, unsigned* __restrict__ ovf = nullptr) {
     constexpr int P = S * S, FQ = F / 4, W = 2 * FQ + F, NT = (P + 15) / 16, CT = F / 16, NSUB = FQ / 16;
     static_assert(P <= 96 && FQ % 16 == 0 && CT % CP == 0, "attention tile geometry");
+    float amax = 0.f;                                                                // X2O: range guard of the fp16 copies (see conv_epilogue_h8)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wave;
     if (b >= rows) return;
@@ -1456,7 +1467,7 @@ __global__ __launch_bounds__(256, TG_ATT_OCC) void k_attention_mfma(const float*
                     if (out2) {
                         h4 hi, lo;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) { hi[q] = (_Float16)u[q]; lo[q] = (_Float16)(u[q] - (float)hi[q]); }
+                        for (int q = 0; q < 4; ++q) { hi[q] = (_Float16)u[q]; lo[q] = (_Float16)(u[q] - (float)hi[q]); amax = __builtin_fmaxf(amax, u[q]); }
                         _Float16* const o16 = reinterpret_cast<_Float16*>(out2);
                         const int c2 = x2_index(c);
                         *reinterpret_cast<h4*>(o16 + h16_index(m, c2, M)) = hi;
@@ -1467,6 +1478,9 @@ __global__ __launch_bounds__(256, TG_ATT_OCC) void k_attention_mfma(const float*
                 }
             }
         }
+    }
+    if constexpr (X2O) {
+        if (__builtin_amdgcn_ballot_w64(!(amax <= 65504.f)) != 0 && lane == 0) atomicAdd(ovf, 1u);
     }
 }
 
@@ -1521,7 +1535,8 @@ __global__ __launch_bounds__(256, 1) void k_attention_x3(const float* __restrict
                                                          const float* __restrict__ wsc_p, const float* __restrict__ gamma,
                                                          const float* __restrict__ bs, const float* __restrict__ bt,
                                                          const float* __restrict__ ps, const float* __restrict__ pt,
-                                                         const float* __restrict__ s2, const float* __restrict__ t2, int rows) {
+                                                         const float* __restrict__ s2, const float* __restrict__ t2, int rows,
+                                                         unsigned* __restrict__ ovf) {
     constexpr int P = S * S, FQ = F / 4, W = 2 * FQ + F, NT = (P + 15) / 16, CT = F / 16, NG = F / 16, NSUB = FQ / 16;
     static_assert(P <= 96 && FQ % 16 == 0 && NG % 2 == 0, "attention tile geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
@@ -1570,7 +1585,10 @@ __global__ __launch_bounds__(256, 1) void k_attention_x3(const float* __restrict
         }
         return p;
     };
-    auto split8 = [&](const f32x4 (&src)[2], const Pro& pr) -> h8 {
+    // range guard (see conv_epilogue_h8): the largest |x| this wave split in phase A (phase B splits the same values again) and the
+    // largest value the epilogue rounds to fp16; checked once per board
+    float amax = 0.f;
+    auto split8 = [&](const f32x4 (&src)[2], const Pro& pr, bool track = false) -> h8 {
         h8 xf;
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
@@ -1579,6 +1597,7 @@ __global__ __launch_bounds__(256, 1) void k_attention_x3(const float* __restrict
 #pragma unroll
                 for (int q = 0; q < 2; ++q) { const float w = v[q] * pr.sc[e >> 2][(e & 3) + q] + pr.sh[e >> 2][(e & 3) + q]; v[q] = w > 0.f ? w : 0.f; }
             }
+            if (track) amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])));
             const f32x2 hi = __builtin_convertvector(__builtin_convertvector(v, h2), f32x2);
             // hi lanes (lo_neg = -0): half(v); lo lanes (lo_neg = -1): half(v - hi), the product is exact either way
             const f32x2 d = {__builtin_fmaf(lo_neg, hi[0], v[0]), __builtin_fmaf(lo_neg, hi[1], v[1])};
@@ -1603,7 +1622,7 @@ __global__ __launch_bounds__(256, 1) void k_attention_x3(const float* __restrict
     auto split = [&](const f32x4 (&src)[NT][2], int g, h8 (&xf)[NT]) {
         const Pro pr = pro_of(g);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) xf[t] = split8(src[t], pr);
+        for (int t = 0; t < NT; ++t) xf[t] = split8(src[t], pr, true);
     };
     int b = blockIdx.x * 4 + wave;
     if (b >= rows) return;
@@ -1838,7 +1857,7 @@ __global__ __launch_bounds__(256, 1) void k_attention_x3(const float* __restrict
                 if (out2) {
                     h4 hi, lo;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { hi[q] = (_Float16)u[q]; lo[q] = (_Float16)(u[q] - (float)hi[q]); }
+                    for (int q = 0; q < 4; ++q) { hi[q] = (_Float16)u[q]; lo[q] = (_Float16)(u[q] - (float)hi[q]); amax = __builtin_fmaxf(amax, u[q]); }
                     *reinterpret_cast<h4*>(hb + (hoE + tn * 256)) = hi;
                     *reinterpret_cast<h4*>(lb + (hoE + tn * 256)) = lo;
                 }
@@ -1846,6 +1865,7 @@ __global__ __launch_bounds__(256, 1) void k_attention_x3(const float* __restrict
             if (ct == 3) TG_ASTAMP(28);
         }
         TG_ASTAMP(26);
+        if (__builtin_amdgcn_ballot_w64(!(amax <= 65504.f)) != 0) { if (lane == 0) atomicAdd(ovf, 1u); amax = 0.f; }
     }
     TG_VMCNT(0);                                                                     // the last board's touches and stores
 }
@@ -2023,9 +2043,9 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                         constexpr int lds3 = (int)(sizeof(_Float16) * F / 16 * WQ * 32 + sizeof(float) * (WQ + 6 * F) + 4096);   // image, parameters, touch scratch
                         const int nwg = (rows + 3) / 4 < 256 ? (rows + 3) / 4 : 256;
                         if (ps) hipLaunchKernelGGL((k_attention_x3<S, F, true>), dim3(nwg), dim3(256), lds3, st, xin, xout, o2, a.x3w, a.qkv.b, a.x3sc,
-                                                   a.gamma, a.s, a.t, ps, pt, sn, tn, rows);
+                                                   a.gamma, a.s, a.t, ps, pt, sn, tn, rows, n->range);
                         else hipLaunchKernelGGL((k_attention_x3<S, F, false>), dim3(nwg), dim3(256), lds3, st, xin, xout, o2, a.x3w, a.qkv.b, a.x3sc,
-                                                a.gamma, a.s, a.t, ps, pt, sn, tn, rows);
+                                                a.gamma, a.s, a.t, ps, pt, sn, tn, rows, n->range);
                         return;
                     }
                 }
@@ -2037,7 +2057,7 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                         hipLaunchKernelGGL((k_conv3x3<S, F, WQ, false, 2, 1>), dim3(grid), dim3(256), 0, st, xin, n->bufQ,
                                            (const float*)nullptr, a.qkv.w, a.qkv.b, (const float*)nullptr, (const float*)nullptr, M);
                     hipLaunchKernelGGL((k_attention_mfma<S, F, 2, true>), dim3((rows + 3) / 4), dim3(256), 0, st, (const float*)n->bufQ, xin, xout,
-                                       reinterpret_cast<float*>(o2), a.gamma, a.s, a.t, ps, pt, sn, tn, rows);
+                                       reinterpret_cast<float*>(o2), a.gamma, a.s, a.t, ps, pt, sn, tn, rows, n->range);
                 }
             };
             const float* s0 = nullptr; const float* t0 = nullptr;
@@ -2045,7 +2065,7 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
             if (act0) { s0 = n->blocks[n->layers[0].ridx].s1; t0 = n->blocks[n->layers[0].ridx].t1; }
             hipLaunchKernelGGL((k_conv3x3_h2<S, 64, F, 4, false, true>), dim3(nblk_h2), dim3(256), 0, st, (const _Float16*)n->x0h, x,
                                act0 ? n->act16 : (_Float16*)nullptr, (const float*)nullptr, (const _Float16*)n->stem_h, n->stem.b, s0, t0,
-                               M, nblk_h2, wsc + 2 * nb);
+                               M, nblk_h2, wsc + 2 * nb, n->range);
             for (size_t i = 0; i < nl; ++i) {
                 const Layer& L = n->layers[i];
                 const float* sn; const float* tn;
@@ -2059,10 +2079,10 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                 { ProfScope ps(n, st, conv_flops);
                   hipLaunchKernelGGL((k_conv3x3_h2<S, 2 * F, F, 0, false, true>), dim3(nblk_h2), dim3(256), 0, st, (const _Float16*)n->act16,
                                      (float*)nullptr, n->h16, (const float*)nullptr, b.h1, b.c1.b, (const float*)nullptr, (const float*)nullptr, M, nblk_h2,
-                                     wsc + 2 * L.ridx); }
+                                     wsc + 2 * L.ridx, n->range); }
                 { ProfScope ps(n, st, conv_flops);
                   hipLaunchKernelGGL((k_conv3x3_h2<S, 2 * F, F, 1, false, true>), dim3(nblk_h2), dim3(256), 0, st, (const _Float16*)n->h16,
-                                     y, act ? n->act16 : (_Float16*)nullptr, (const float*)x, b.h2, b.c2.b, sn, tn, M, nblk_h2, wsc + 2 * L.ridx + 1); }
+                                     y, act ? n->act16 : (_Float16*)nullptr, (const float*)x, b.h2, b.c2.b, sn, tn, M, nblk_h2, wsc + 2 * L.ridx + 1, n->range); }
                 float* t = x; x = y; y = t;
             }
             // the head conv is 16 couts wide (one MFMA tile): the f32 kernel reads the f32 residual stream and activates while staging
@@ -2099,11 +2119,11 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
             if (r16)
                 hipLaunchKernelGGL((k_conv3x3_h2<S, 64, F, 4, true>), dim3(grid_h2), dim3(256), 0, st, (const _Float16*)n->x0h, x, n->act16,
                                    (const float*)nullptr, (const _Float16*)n->stem_h, n->stem.b, nb ? n->blocks[0].s1 : n->s_end,
-                                   nb ? n->blocks[0].t1 : n->t_end, M, nblk_h2);
+                                   nb ? n->blocks[0].t1 : n->t_end, M, nblk_h2, (const float*)nullptr, n->range);
             else
                 hipLaunchKernelGGL((k_conv3x3_h2<S, 64, F, 4>), dim3(grid_h2), dim3(256), 0, st, (const _Float16*)n->x0h, x, n->act16,
                                    (const float*)nullptr, (const _Float16*)n->stem_h, n->stem.b, nb ? n->blocks[0].s1 : n->s_end,
-                                   nb ? n->blocks[0].t1 : n->t_end, M, nblk_h2);
+                                   nb ? n->blocks[0].t1 : n->t_end, M, nblk_h2, (const float*)nullptr, n->range);
             for (size_t i = 0; i < nb; ++i) {
                 const BlockW& b = n->blocks[i];
                 const bool last = i + 1 == nb;
@@ -2112,14 +2132,15 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                 _Float16* const a16 = n->act16;
                 { ProfScope ps(n, st, conv_flops);
                   hipLaunchKernelGGL((k_conv3x3_h2<S, F, F, 0>), dim3(grid_h2), dim3(256), 0, st, (const _Float16*)n->act16,
-                                     (float*)nullptr, n->h16, (const float*)nullptr, b.h1, b.c1.b, (const float*)nullptr, (const float*)nullptr, M, nblk_h2); }
+                                     (float*)nullptr, n->h16, (const float*)nullptr, b.h1, b.c1.b, (const float*)nullptr, (const float*)nullptr, M, nblk_h2,
+                                     (const float*)nullptr, n->range); }
                 { ProfScope ps(n, st, conv_flops);
                   if (r16)
                       hipLaunchKernelGGL((k_conv3x3_h2<S, F, F, 1, true>), dim3(grid_h2), dim3(256), 0, st, (const _Float16*)n->h16,
-                                         last ? (float*)nullptr : y, a16, (const float*)x, b.h2, b.c2.b, sn, tn, M, nblk_h2);
+                                         last ? (float*)nullptr : y, a16, (const float*)x, b.h2, b.c2.b, sn, tn, M, nblk_h2, (const float*)nullptr, n->range);
                   else
                       hipLaunchKernelGGL((k_conv3x3_h2<S, F, F, 1>), dim3(grid_h2), dim3(256), 0, st, (const _Float16*)n->h16,
-                                         last ? (float*)nullptr : y, a16, (const float*)x, b.h2, b.c2.b, sn, tn, M, nblk_h2); }
+                                         last ? (float*)nullptr : y, a16, (const float*)x, b.h2, b.c2.b, sn, tn, M, nblk_h2, (const float*)nullptr, n->range); }
                 float* t = x; x = y; y = t;
             }
             hipLaunchKernelGGL((k_head_h<S, F>), dim3(grid_h), dim3(256), 0, st, (const _Float16*)n->act16, n->hc,
@@ -2356,6 +2377,8 @@ int fill_weight_set(tg_ctx* ctx, Net* n, int k, const float* blob, hipStream_t s
         // (asynchronous) restaging starts
         TG_HIP(ctx, hipStreamSynchronize(st));
     }
+    TG_HIP(ctx, hipMemsetAsync(n->range + 1 + k, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(k_absmax, dim3(256), dim3(256), 0, st, (const float*)n->sets[k].blob, n->blob_floats, n->range + 1 + k);
     Net view = *n;                                        // pointer fields of set k without disturbing the live binding
     bind_weights(&view, k);
     hipLaunchKernelGGL(k_restage_head, dim3(64), dim3(256), 0, st, view.head.w, n->sets[k].head_g, F);
@@ -2478,6 +2501,8 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
         TG_HIP(ctx, hipMalloc((void**)&n->x0, sizeof(float) * (size_t)rows_cap * P * 16));
         TG_HIP(ctx, hipMalloc((void**)&n->hc, sizeof(float) * (size_t)rows_cap * P * 16));
         TG_HIP(ctx, hipMalloc((void**)&n->own, sizeof(float) * (size_t)rows_cap * P));
+        TG_HIP(ctx, hipMalloc((void**)&n->range, sizeof(unsigned) * 4));
+        TG_HIP(ctx, hipMemset(n->range, 0, sizeof(unsigned) * 4));
 
         if (any_att) TG_HIP(ctx, hipMalloc((void**)&n->bufQ, sizeof(float) * (size_t)rows_cap * P * Wq));
         if (pol) TG_HIP(ctx, hipMalloc((void**)&n->hca, sizeof(float) * (size_t)rows_cap * P * 16));
@@ -2602,7 +2627,7 @@ void tg_net_destroy(tg_ctx* ctx) {
     if (!ctx || !ctx->eng || !ctx->eng->net) return;
     Net* n = ctx->eng->net;
     if (n->pending) (void)hipEventSynchronize(n->loaded);
-    void* ptrs[] = {n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->bufQ, n->hca, n->bufAct, n->act16, n->h16, n->x0h, n->tile_ctr};
+    void* ptrs[] = {n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->bufQ, n->hca, n->bufAct, n->act16, n->h16, n->x0h, n->tile_ctr, n->range};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (Net::WeightSet& w : n->sets) { void* q[] = {w.blob, w.wstage, w.wh, w.stem_h, w.head_h, w.wsc, w.head_g, w.head_ag, w.att_h, w.att_sc}; for (void* p : q) if (p) (void)hipFree(p); }
     if (n->side) (void)hipStreamDestroy(n->side);
@@ -2656,6 +2681,26 @@ int tg_net_predict(tg_ctx* ctx, const float* obs, int n_rows, float* policy, flo
     return TG_OK;
 }
 
+
+// Range report (the reference runs f32 end to end, model.py:79-114, and hands over arbitrary trained checkpoints, model.py:23-27;
+// the fp16-carrying precisions do not have f32's range).  fp16_overflows: sticky count, since the network was created, of epilogue
+// tiles (convs) / boards (attention) in which a value beyond +-65504 was rounded to fp16 -- from there on the network computes
+// inf / NaN; 0 = every forward pass so far stayed in range.  Always 0 with net_precision 0.  weight_absmax: largest |w| of the
+// live weight set's BN-folded blob (inf / NaN if the blob holds one).  A non-zero count also leaves a message in tg_last_error.
+int tg_net_range(tg_ctx* ctx, uint64_t* fp16_overflows, float* weight_absmax) {
+    if (!ctx || !ctx->eng || !ctx->eng->net) return TG_ERR_STATE;
+    Net* n = ctx->eng->net;
+    TG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    unsigned host[4] = {0, 0, 0, 0};
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    TG_HIP(ctx, hipMemcpy(host, n->range, sizeof(host), hipMemcpyDeviceToHost));
+    if (fp16_overflows) *fp16_overflows = host[0];
+    if (weight_absmax) { float f; memcpy(&f, &host[1 + n->active], sizeof(f)); *weight_absmax = f; }
+    if (host[0])
+        ctx->err = "fp16 overflow: " + std::to_string(host[0]) + " epilogue tiles rounded a value beyond +-65504 to fp16 (net_precision " +
+                   std::to_string(n->prec) + "); outputs since then may be inf/NaN -- use net_precision 0 for these weights";
+    return TG_OK;
+}
 
 // HIP-event timing of the dominant kernel (3x3 conv F->F), measured on the stream the kernels are launched on.
 int tg_prof_enable(tg_ctx* ctx, int on, int max_launches) {

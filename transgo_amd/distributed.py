@@ -3,9 +3,14 @@
 finished games' (s, pi, z) material to the rank that owns the replay buffer -- the Ray `mem.append.remote` traffic of
 self_play.py:943-965.  What travels is `records.Harvest`'s flat buffer: bit-packed observation planes (10*S*S bits), raw
 visit counts (pi = counts/sum is recomputed bit-identically at the owner), z, territory from the mover's side and the
-per-game tables.  With RCCL the buffer is the very device tensor `tg_sp_harvest` filled, sent rank-to-rank at its exact
-length (grouped send/recv, no padding to the largest rank, no host staging); the 8-fold augmentation happens after the
-gather, at the consumer."""
+per-game tables.  With RCCL the buffer is the very device tensor `tg_sp_harvest` filled (no host staging); the 8-fold
+augmentation happens after the gather, at the consumer.
+
+Transport of the payloads (TRANSGO_GATHER): "allgather" (default) = ONE plain `all_gather` of the buffers padded to the
+longest rank's -- the collective every RCCL build runs on first contact; ~2 MB per rank and move at C2 against a 3.4-s move,
+so the padding costs nothing measurable.  "p2p" = grouped isend/irecv to the owner at exact lengths (no padding, nothing
+delivered to ranks that do not need it): opt-in until it has run between two RCCL ranks on hardware (it is covered over
+gloo).  `transport_name()` is what bench.py prints in `ranks.transport`."""
 import os
 
 import numpy as np
@@ -13,6 +18,18 @@ import torch
 import torch.distributed as dist
 
 from . import records
+
+
+def _transport():
+    t = os.environ.get("TRANSGO_GATHER", "allgather")
+    if t not in ("allgather", "p2p"):
+        raise ValueError(f"TRANSGO_GATHER={t!r}: expected 'allgather' or 'p2p'")
+    return t
+
+
+def transport_name():
+    return {"allgather": "all_gather of harvest buffers padded to the longest rank's (default)",
+            "p2p": "grouped isend/irecv to the owner at exact lengths (TRANSGO_GATHER=p2p)"}[_transport()]
 
 
 def _active():
@@ -84,8 +101,8 @@ def _gather_payloads(h, S, C, dst, sizes, world, rank, nccl, dev):
             b = torch.from_numpy(b)
         return b.to(dev) if b.device != dev else b
 
-    if os.environ.get("TRANSGO_GATHER", "p2p") == "allgather":
-        # fallback transport (plain collective only): every rank contributes its buffer padded to the longest one
+    if _transport() == "allgather":
+        # default transport (plain collective only): every rank contributes its buffer padded to the longest one
         mx = max(records.layout(S, C, g, n)[1] if g else 0 for g, n in sizes)
         pad = torch.zeros(mx, dtype=torch.uint8, device=dev)
         if h is not None:

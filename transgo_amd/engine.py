@@ -291,5 +291,16 @@ class SelfPlayEngine:
         self.ctx.call("tg_sp_stats", *[ctypes.byref(x) for x in v], ctypes.byref(e), ctypes.byref(m))
         tr = ctypes.c_uint64()
         self.ctx.call("tg_sp_tree_truncations", ctypes.byref(tr))
-        return dict(sims=v[0].value, evals=v[1].value, depth_sum=v[2].value, tie_draws=v[3].value, errors=e.value,
-                    max_slots=m.value, truncated_blocks=tr.value)
+        out = dict(sims=v[0].value, evals=v[1].value, depth_sum=v[2].value, tie_draws=v[3].value, errors=e.value,
+                   max_slots=m.value, truncated_blocks=tr.value, fp16_overflows=0)
+        if self.evaluator is None:
+            out["fp16_overflows"] = self.net_range()["fp16_overflows"]
+        return out
+
+    def net_range(self):
+        """tg_net_range: sticky count of output tiles in which a value beyond +-65504 was rounded to fp16 (net_precision 1-3; 0 = every
+        forward pass so far stayed in range) and the largest |w| of the live BN-folded weight blob."""
+        n = ctypes.c_uint64(); w = ctypes.c_float()
+        if self.ctx.lib.tg_net_range(self.ctx.h, ctypes.byref(n), ctypes.byref(w)) != 0:
+            return {"fp16_overflows": 0, "weight_absmax": None}              # no network loaded in this context (yet)
+        return {"fp16_overflows": int(n.value), "weight_absmax": float(w.value)}

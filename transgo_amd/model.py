@@ -142,9 +142,27 @@ def pack_weights(sd, board_size, encode_dim, filters, blocks=None, prefix="main_
 
 
 def load_into(ctx, sd, board_size, encode_dim, filters, blocks=None, rows_cap=0, arch=None):
+    """pack + tg_net_load_arch.  Returns the range of what was loaded, {"weight_absmax", "finite"} of the BN-folded blob: the
+    reference hands over arbitrary trained checkpoints (model.py:23-27) and runs them in f32; net_precision 1 / 2 store weights as
+    fp16 (|w| > 65504 -> inf) and every fp16-carrying mode can overflow its activations (tg_net_range counts that at run time), so
+    a blob that is not finite, or too large for the context's precision, is reported at once (warnings.warn) instead of surfacing
+    later as NaN priors in the tree."""
     arch = arch or tower_arch(blocks)
     blob = pack_weights(sd, board_size, encode_dim, filters, arch=arch)
     ctx.call("tg_net_load_arch", arch.code.encode(), blob.ctypes.data_as(ctypes.c_void_p), blob.size, rows_cap)
+    return weight_range(blob, int(ctx.cfg.net_precision))
+
+
+def weight_range(blob, net_precision=0):
+    import warnings
+    amax = float(np.max(np.abs(blob))) if blob.size else 0.0
+    rng = {"weight_absmax": amax, "finite": bool(np.isfinite(amax))}
+    if not rng["finite"]:
+        warnings.warn("network weights contain inf/NaN after BatchNorm folding: every evaluation will be NaN", RuntimeWarning)
+    elif net_precision in (1, 2) and amax > 65504.0:
+        warnings.warn(f"BN-folded weights reach |w| = {amax:.4g}, beyond fp16 (net_precision {net_precision} stores them as fp16): "
+                      "use inference_dtype 'f32' or 'f32x3' for this checkpoint", RuntimeWarning)
+    return rng
 
 
 # tg_config.net_precision: "f16" = fp16 weights/activations in HBM and LDS with f32 accumulation and an f32 residual stream
@@ -169,7 +187,15 @@ class HipNetwork:
 
     def set_weights(self, weights):                      # model.py:26-27
         self._weights = weights
-        load_into(self.ctx, weights, self.S, self.C, self.F, rows_cap=self.rows_cap, arch=self.arch)
+        self.weight_range = load_into(self.ctx, weights, self.S, self.C, self.F, rows_cap=self.rows_cap, arch=self.arch)
+        return self.weight_range
+
+    def net_range(self):
+        """tg_net_range: {"fp16_overflows": sticky count of output tiles that rounded a value beyond +-65504 to fp16 (0 with
+        precision "f32"), "weight_absmax": largest |w| of the live BN-folded blob as the device sees it}."""
+        n = ctypes.c_uint64(); w = ctypes.c_float()
+        self.ctx.call("tg_net_range", ctypes.byref(n), ctypes.byref(w))
+        return {"fp16_overflows": int(n.value), "weight_absmax": float(w.value)}
 
     def get_weights(self):                               # model.py:23-24
         return self._weights

@@ -117,7 +117,9 @@ class BatchedSelfPlay:
             self.arch = _model.transgo_arch()
         elif "main_network.res_blocks.0.conv_1.weight" in state_dict and self.arch.policy_attention:
             self.arch = _model.tower_arch(self.blocks)
-        _model.load_into(self.engine.ctx, state_dict, self.S, self.config.encode_state_channels, self.filters, arch=self.arch)
+        self.weight_range = _model.load_into(self.engine.ctx, state_dict, self.S, self.config.encode_state_channels, self.filters,
+                                             arch=self.arch)
+        return self.weight_range
 
     def set_weights_blob(self, blob, background=False):
         """Packed blob -> GPU.  background=True: upload into the idle weight set on a side stream (tg_net_load_async) while

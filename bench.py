@@ -190,8 +190,12 @@ def parse_args(argv=None):
                          "roofline figures are defined on (with K > 1 launches of different groups share the chip, so per-launch "
                          "durations are no longer exclusive and `roofline` says so)")
     ap.add_argument("--arena-slots", type=int, default=0,
-                    help="32-byte tree slots per game and half arena (default: (4*sims + 256) * (header + actions)); the line reports "
-                         "the high-water mark and any truncated tree blocks, so a 19x19 run can be sized for more boards per GPU")
+                    help="most 32-byte tree slots ONE game's tree may hold (per-game cap; default: (4*sims + 256) * (header + actions)); "
+                         "memory is set by --pool-slots")
+    ap.add_argument("--pool-slots", type=int, default=0,
+                    help="tree memory: 32-byte slots provisioned per game ON AVERAGE in the pool all boards of a GPU share (default: "
+                         "(2*sims + 128) * (header + actions)); the line reports the pool's size, its high-water mark, how often it "
+                         "ran empty and any truncated tree blocks, so a run can be sized for more boards per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=0.0,
                     help="window of each CPU-baseline leg (default: 60 s at N = 1 as BASELINE.md 4 says, 30 s at N > 1)")
@@ -306,6 +310,7 @@ def _secondary_summary(line, wall_s):
             "net_tflops_end_to_end": ex.get("net_tflops_end_to_end"), "leaves_per_s": ex.get("leaves_per_s"),
             "tree_errors": ex.get("tree_errors"), "fp16_overflows": ex.get("fp16_overflows"),
             "truncated_tree_blocks": ex.get("truncated_tree_blocks"), "arena_high_water_slots": ex.get("arena_high_water_slots"),
+            "tree_pool": ex.get("tree_pool"),
             "leg_wall_s": round(wall_s, 1)}
 
 
@@ -424,10 +429,11 @@ def main(argv=None):
         # sub-tree blocks at re-rooting (counted in truncated_tree_blocks; DESIGN.md 3 "Sizing") -- twice the default holds them all
         a.arena_slots = 2 * (4 * a.sims + 256) * ((2 if S == 9 else 4) + S * S + 1)
     if a.groups > 1:
-        sp = GroupedSelfPlay(cfg, a.games, groups=a.groups, device=gpu, rank=rank, world=world, arena_slots=a.arena_slots)
+        sp = GroupedSelfPlay(cfg, a.games, groups=a.groups, device=gpu, rank=rank, world=world, arena_slots=a.arena_slots,
+                             pool_slots=a.pool_slots)
         parts = sp.parts
     else:
-        sp = BatchedSelfPlay(cfg, a.games, device=gpu, rank=rank, world=world, arena_slots=a.arena_slots)
+        sp = BatchedSelfPlay(cfg, a.games, device=gpu, rank=rank, world=world, arena_slots=a.arena_slots, pool_slots=a.pool_slots)
         parts = [sp]
     if a.network == "transgo":
         sp.set_weights(model.random_transgo_weights(S, 10, a.filters, seed=1234))
@@ -615,7 +621,12 @@ def main(argv=None):
                       "net_tflops_end_to_end": round(evals_all * fpl / dt / 1e12, 2) if fpl else None,
                       "tree_errors": st1["errors"], "fp16_overflows": st1["fp16_overflows"],
                       "arena_high_water_slots": st1["max_slots"],
-                      "arena_slots_per_half": int(eng.ctx.cfg.arena_slots) or (4 * a.sims + 256) * ((2 if S == 9 else 4) + S * S + 1),
+                      "arena_cap_slots_per_game": int(eng.ctx.cfg.arena_slots) or (4 * a.sims + 256) * ((2 if S == 9 else 4) + S * S + 1),
+                      "tree_pool": {"slots": st1["pool_slots"], "gib": round(st1["pool_slots"] * 32 / 2 ** 30, 2),
+                                    "high_water_slots": st1["pool_high_water"], "high_water_frac": round(st1["pool_high_water"] / max(1, st1["pool_slots"]), 4),
+                                    "ran_empty": st1["pool_exhausted"],
+                                    "note": "one pool of 32-byte slots per engine context, shared by its boards (chunks of 1024 slots at 9x9, "
+                                            "4096 at 19x19); arena_high_water_slots = the largest single tree"},
                       "truncated_tree_blocks": st1["truncated_blocks"],
                       "step_phases_ms": dict({k: round(v / a.steps * 1e3, 2) for k, v in phase_s.items()},
                                              begin_move_inside_search=round(begin_move_s / a.steps * 1e3, 2)),

@@ -50,7 +50,8 @@ typedef struct tg_config {
     int32_t wu_loss;            /* configure.py:32 (2) */
     double c_puct1;             /* configure.py:26 (3) */
     double c_puct2;             /* configure.py:27 (0.05) */
-    int32_t arena_slots;        /* 32-byte tree slots per game per half arena; 0 = (4*num_simulation + 256) blocks of the largest size */
+    int32_t arena_slots;        /* most 32-byte tree slots ONE game's tree may hold (per-game cap); 0 = (4*num_simulation + 256) blocks of
+                                   the largest size.  Memory is set by pool_slots below, not by this */
     int32_t net_blocks;         /* residual blocks of the tower (BASELINE.json "N-block x F-filter") */
     int32_t net_filters;        /* channels F (multiple of 32) */
     int32_t device;             /* HIP device ordinal */
@@ -62,7 +63,11 @@ typedef struct tg_config {
                                    attention layers at 9x9 (the reference's MainNetwork), anything else is refused by tg_net_load */
     int32_t record_games;       /* 1 (default): every game's move record -- env.encode(root) bit-packed, raw visit counts, side to
                                    move; the three Python lists of self_play.py:917-926 -- is kept in HBM for tg_sp_harvest */
-    int32_t reserved[6];
+    int32_t pool_slots;         /* tree memory: 32-byte slots provisioned PER GAME ON AVERAGE in the pool all games of the context share
+                                   (pool = n_games x this; a game takes chunks from it as its tree grows and returns them when it is
+                                   re-rooted or restarted); 0 = (2*num_simulation + 128) blocks of the largest size.  tg_sp_pool_stats
+                                   reports the fill; a game that finds the pool empty is parked like one that hits its cap */
+    int32_t reserved[5];
 } tg_config;
 
 void tg_config_default(tg_config* cfg);
@@ -173,6 +178,12 @@ int tg_sp_game_errors(tg_ctx* ctx, int32_t* n_errors, int32_t* err /*[G] or NULL
  * moves in a row) its deepest blocks are dropped: those nodes keep their statistics and become unexpanded leaves again.
  * blocks = how many were dropped so far over all games (0 = every search so far equals the reference's). */
 int tg_sp_tree_truncations(tg_ctx* ctx, uint64_t* blocks);
+
+/* Tree memory.  The reference keeps every tree in unbounded Python memory (Node_V objects, self_play.py:51-95); here all games of
+ * a context share ONE pool of cfg.pool_slots x n_games slots.  pool_slots = its size; high_water_slots = the most that was in use
+ * at once since creation; in_use_slots = now; exhausted = how often a game found no chunk left (that game is then parked in error
+ * 1, tg_sp_game_errors, or its kept sub-tree truncated, tg_sp_tree_truncations -- 0 = never).  Any pointer may be NULL. */
+int tg_sp_pool_stats(tg_ctx* ctx, uint64_t* pool_slots, uint64_t* high_water_slots, uint64_t* in_use_slots, uint64_t* exhausted);
 
 /* ---- finished games -> training positions, on the device (self_play.py:929-967) ------------------------------------------
  * Games the LAST tg_sp_play finished, in ascending slot order, and the number of recorded positions (= moves) they hold. */

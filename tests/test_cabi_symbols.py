@@ -114,15 +114,26 @@ def test_device_code_has_no_out_of_line_calls(tmp_path):
     """Round 3 (DESIGN.md, 19x19 fault): one out-of-line device function call (k_play<19> -> the ballot-packed encode_bits<19>)
     corrupted state silently and made the next kernel fault; the same body inlined is fine.  Since then every device helper is
     __forceinline__ and this test keeps it that way: no s_swappc_b64 (call) in any gfx950 code object of the shipped library."""
+    import glob
     import shutil
     import struct
     import subprocess
-    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-    if not os.path.exists(objdump):
-        pytest.skip("llvm-objdump not available")
+    # llvm-objdump through ROCM_PATH / hipconfig / PATH; a library that holds device code but cannot be disassembled FAILS the
+    # test (this check is the only guard against the fault's return: it must not turn itself off silently)
+    cands = [os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "llvm-objdump")]
+    try:
+        hp = subprocess.run(["hipconfig", "--rocmpath"], stdout=subprocess.PIPE, text=True, timeout=30).stdout.strip()
+        if hp:
+            cands.append(os.path.join(hp, "lib", "llvm", "bin", "llvm-objdump"))
+    except (OSError, subprocess.SubprocessError):
+        pass
+    cands += sorted(glob.glob("/opt/rocm*/lib/llvm/bin/llvm-objdump")) + [shutil.which("llvm-objdump") or ""]
+    objdump = next((c for c in cands if c and os.path.exists(c)), None)
     data = open(_lib.LIB_PATH, "rb").read()
     magic = b"__CLANG_OFFLOAD_BUNDLE__"
-    pos, n_objs, calls = 0, 0, 0
+    assert magic in data, "the shipped library holds no device code bundle"
+    assert objdump, "llvm-objdump not found (ROCM_PATH, hipconfig --rocmpath, /opt/rocm*, PATH): the library's device code cannot be checked"
+    pos, n_objs, calls, targets = 0, 0, 0, set()
     while True:
         i = data.find(magic, pos)
         if i < 0:
@@ -132,12 +143,15 @@ def test_device_code_has_no_out_of_line_calls(tmp_path):
         for _ in range(nb):
             o, sz, tl = struct.unpack_from("<QQQ", data, off); off += 24
             triple = data[off:off + tl].decode(); off += tl
-            if "gfx950" in triple and sz:
+            if "amdgcn" in triple and sz:                    # EVERY device target of the bundle, whatever ARCH the Makefile was given
                 f = tmp_path / f"co{n_objs}.o"
                 f.write_bytes(data[i + o:i + o + sz])
                 out = subprocess.run([objdump, "-d", str(f)], stdout=subprocess.PIPE, text=True, check=True).stdout
+                assert "s_endpgm" in out, f"{triple}: disassembly shows no kernel"
                 calls += out.count("s_swappc_b64")
                 n_objs += 1
+                targets.add(triple.split("--")[-1])
         pos = i + 24
-    assert n_objs >= 4, "expected one gfx950 code object per .hip source"
+    assert targets, "no amdgcn code object in the library"
+    assert n_objs >= 4 * len(targets), f"expected one code object per .hip source and target, found {n_objs} for {sorted(targets)}"
     assert calls == 0, f"{calls} out-of-line device calls in the library"

@@ -295,3 +295,51 @@ def test_wp_mcts_mirror_reset_root_keeps_the_random_stream():
     assert np.array_equal(key, ok) and pos == opos
     assert games[0] != games[1] and games[1] != games[2]          # re-seeding every game would make them identical
     m.close()
+
+
+def test_tree_pool_is_shared_accounted_and_survives_exhaustion():
+    """Round 4: all games of a context take their tree chunks from ONE pool (provisioned for the population, not for the worst game
+    times the number of games).  (1) accounting: after a full reset every game owns exactly one chunk; searching grows the fill,
+    re-rooting returns the old trees, a full reset returns everything.  (2) a pool far too small for its games: games that find it
+    empty are parked and reported exactly like games that hit their own cap -- nothing faults, the others finish their searches,
+    restarting the parked slots works -- and the games that did fit searched exactly what the same seeds search in a roomy pool."""
+    from transgo_amd.engine import SelfPlayEngine
+    G, sims, CH = 48, 64, 1024
+    roomy = SelfPlayEngine(G, num_simulation=sims, evaluator=evaluators.sharp)
+    roomy.reset(np.arange(G))
+    p0 = roomy.pool_stats()
+    assert p0["pool_in_use"] == G * CH and p0["pool_exhausted"] == 0 and p0["pool_slots"] >= G * (2 * sims + 128) * 84
+    roomy.search()
+    vis_r, st_r = roomy.root_visits()
+    p1 = roomy.pool_stats()
+    assert p1["pool_in_use"] > p0["pool_in_use"] and p1["pool_high_water"] >= p1["pool_in_use"] and p1["pool_exhausted"] == 0
+    acts = roomy.choose_moves(vis_r, st_r)[0]
+    roomy.play(acts)
+    p2 = roomy.pool_stats()
+    assert p2["pool_in_use"] < p1["pool_in_use"]                  # the old trees went back, the kept sub-trees are smaller
+    assert p2["pool_high_water"] >= p1["pool_in_use"]
+    roomy.reset(np.arange(G))
+    assert roomy.pool_stats()["pool_in_use"] == G * CH
+    s = roomy.stats()
+    assert s["errors"] == 0 and s["pool_exhausted"] == 0 and s["max_slots"] % CH == 0 and s["max_slots"] >= 2 * CH
+    # the smallest pool the library accepts: 2 chunks per game + one largest tree
+    tiny = SelfPlayEngine(G, num_simulation=sims, evaluator=evaluators.sharp, pool_slots=1)
+    tiny.reset(np.arange(G))
+    t0 = tiny.pool_stats()
+    assert t0["pool_slots"] < p0["pool_slots"] / 4 and t0["pool_in_use"] == G * CH
+    tiny.search()
+    err = tiny.game_errors()
+    t1 = tiny.pool_stats()
+    assert t1["pool_exhausted"] > 0 and 0 < (err != 0).sum() < G and ((err == 0) | (err == 1)).all()
+    assert t1["pool_in_use"] <= t1["pool_slots"]
+    vis_t, st_t = tiny.root_visits()
+    ok = err == 0
+    assert (vis_t[ok] == vis_r[ok]).all()                         # where the pool sufficed, the same search as in the roomy pool
+    done = tiny.play(tiny.choose_moves(vis_t, st_t)[0])
+    assert (tiny.errored == (err != 0)).all() and not done[ok].any()
+    tiny.reset(np.arange(100, 100 + G), tiny.errored)              # the parked slots start new games with the chunks play() returned
+    assert tiny.stats()["errors"] == 0
+    tiny.search(num_simulation=2)                                  # the engine goes on (which games fit next is up to the pool)
+    t2 = tiny.pool_stats()
+    assert t2["pool_in_use"] <= t2["pool_slots"] and t2["pool_high_water"] <= t2["pool_slots"]
+    roomy.close(); tiny.close()

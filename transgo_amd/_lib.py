@@ -15,7 +15,7 @@ class TgConfig(ctypes.Structure):
                 ("parallel_readouts", ctypes.c_int32), ("wu_loss", ctypes.c_int32), ("c_puct1", ctypes.c_double),
                 ("c_puct2", ctypes.c_double), ("arena_slots", ctypes.c_int32), ("net_blocks", ctypes.c_int32),
                 ("net_filters", ctypes.c_int32), ("device", ctypes.c_int32), ("net_precision", ctypes.c_int32),
-                ("record_games", ctypes.c_int32), ("reserved", ctypes.c_int32 * 6)]
+                ("record_games", ctypes.c_int32), ("pool_slots", ctypes.c_int32), ("reserved", ctypes.c_int32 * 5)]
 
 
 class TgMt19937(ctypes.Structure):
@@ -63,6 +63,7 @@ SIGNATURES = {
     "tg_sp_final": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "tg_sp_game_errors": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), _vp]),
     "tg_sp_tree_truncations": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
+    "tg_sp_pool_stats": (ctypes.c_int, [_vp] + [ctypes.POINTER(ctypes.c_uint64)] * 4),
     "tg_sp_finished": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "tg_sp_harvest": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     "tg_sp_stats": (ctypes.c_int, [_vp] + [ctypes.POINTER(ctypes.c_uint64)] * 4 + [ctypes.POINTER(ctypes.c_int32)] * 2),

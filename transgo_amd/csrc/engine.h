@@ -12,7 +12,10 @@ enum BatchKind { BATCH_NONE = 0, BATCH_ROOTS = 1, BATCH_LEAVES = 2 };
 
 // Everything the tree kernels need, passed by value.
 struct EngineDev {
-    NodeRec* arena = nullptr;       // [G][2][arena_slots]
+    NodeRec* arena = nullptr;       // the chunk pool: [pool_chunks][chunk_slots] (tree_dev.h)
+    int32_t* ring = nullptr;        // [pool_chunks] free ring of chunk ids
+    PoolCtl* pool = nullptr;        // its counters
+    int32_t* chunk_ids = nullptr;   // [G][2][max_chunks] chunk-id lists of the games' trees
     GameCtl* ctl = nullptr;         // [G]
     tg_mt19937* rng = nullptr;      // [G]  NumPy-legacy MT19937 stream per game
     int32_t* path_nodes = nullptr;  // [G][R][maxd]

@@ -35,6 +35,7 @@ __device__ unsigned long long g_stamp[16], g_stamp2[8];
 
 // ---- device helpers -------------------------------------------------------------------------------------------------------
 constexpr int kMaxPath = 512;                        // longest selection path kept in LDS (>= SearchCfg::maxd, checked at create)
+constexpr int kMaxChunks = 2048;                     // most chunks one game's tree may own (>= SearchCfg::max_chunks, checked at create)
 
 // The record lane `src` (wave-uniform) holds, for every lane.
 __device__ __forceinline__ NodeRec bcast_rec(const NodeRec& r, int src) {
@@ -45,17 +46,81 @@ __device__ __forceinline__ NodeRec bcast_rec(const NodeRec& r, int src) {
     return __builtin_bit_cast(NodeRec, out);
 }
 
-template <int S> __device__ __forceinline__ NodeRec* arena_of(NodeRec* base, int g, int half, int slots) {
-    return base + ((size_t)g * 2 + half) * (size_t)slots;
-}
 template <int S> __device__ __forceinline__ BlockHdr<S>* hdr_of(NodeRec* arena, int blk) {
     return reinterpret_cast<BlockHdr<S>*>(arena + blk);
+}
+
+// ---- chunk pool (tree_dev.h) -------------------------------------------------------------------------------------------
+// One chunk id off the free ring, or -1 when no chunk is visible (lane 0 calls it).  Only entries published before this launch
+// are taken, so the entry read here was written by an earlier kernel.
+__device__ __forceinline__ int pool_pop(const EngineDev& d) {
+    PoolCtl* pc = d.pool;
+    const unsigned long long vis = pc->visible;
+    unsigned long long h = __hip_atomic_load(&pc->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if (h >= vis) { atomicAdd(&pc->exhausted, 1ull); return -1; }
+        const unsigned long long old = atomicCAS(&pc->head, h, h + 1);
+        if (old == h) break;
+        h = old;
+    }
+    return d.ring[h % (unsigned long long)d.sc.pool_chunks];
+}
+// n chunk ids back onto the ring (whole wave; poppable once k_pool_publish has run behind this kernel)
+__device__ __forceinline__ void pool_push(const EngineDev& d, const int32_t* ids, int n) {
+    if (n <= 0) return;
+    const int lane = lane_id();
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&d.pool->tail, (unsigned long long)n);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32));
+    base = ((unsigned long long)hi << 32) | lo;
+    for (int i = lane; i < n; i += 64) d.ring[(base + i) % (unsigned long long)d.sc.pool_chunks] = ids[i];
+}
+__global__ void k_pool_init(EngineDev d) {
+    const int n = d.sc.pool_chunks;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d.ring[i] = i;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        PoolCtl pc; pc.head = 0; pc.tail = pc.visible = (unsigned long long)n; pc.min_free = (unsigned long long)n; pc.exhausted = 0;
+        *d.pool = pc;
+    }
+}
+// behind every kernel that pushes (k_play, k_reset): what it pushed becomes poppable; the fill just before is the cycle's peak
+__global__ void k_pool_publish(EngineDev d) {
+    PoolCtl* pc = d.pool;
+    const unsigned long long fr = pc->visible - pc->head;
+    if (fr < pc->min_free) pc->min_free = fr;
+    pc->visible = pc->tail;
+}
+
+// A tree under construction / growing: the chunk-id list it records its chunks in and the bump pointer inside the newest chunk.
+struct TreeAlloc {
+    int32_t* ids; int n_chunks, free_slot, chunk_end;
+};
+// n contiguous slots (n <= chunk_slots) for the tree, from its current chunk or a fresh one off the pool; -1 = the game's cap
+// (max_chunks) or the pool is exhausted.  Called by the whole wave; every lane gets the same answer.
+__device__ __forceinline__ int tree_alloc(const EngineDev& d, TreeAlloc& al, int n) {
+    if (al.free_slot + n > al.chunk_end) {
+        if (al.n_chunks >= d.sc.max_chunks) return -1;
+        int id = -1;
+        if (lane_id() == 0) id = pool_pop(d);
+        id = __builtin_amdgcn_readfirstlane(id);
+        if (id < 0) return -1;
+        if (lane_id() == 0) al.ids[al.n_chunks] = id;
+        ++al.n_chunks;
+        al.free_slot = id * d.sc.chunk_slots;
+        al.chunk_end = al.free_slot + d.sc.chunk_slots;
+    }
+    const int at = al.free_slot;
+    al.free_slot = __builtin_amdgcn_readfirstlane(al.free_slot + n);
+    return at;
+}
+__device__ __forceinline__ int32_t* chunk_list(const EngineDev& d, int g, int which) {
+    return d.chunk_ids + ((size_t)g * 2 + which) * (size_t)d.sc.max_chunks;
 }
 
 // Allocate and write the block of a node whose position `st` is loaded + analysed in `bw`: header + one fresh child
 // record per legal action (Node_V.expand with prior 0.0, self_play.py:70-77, :634-636).  Returns the block slot or -1.
 template <int S>
-__device__ __forceinline__ int make_block(BoardWave<S>& bw, const BoardState<S>& st, NodeRec* arena, int& free_slot, int cap, bool children) {
+__device__ __forceinline__ int make_block(BoardWave<S>& bw, const BoardState<S>& st, NodeRec* arena, const EngineDev& d, TreeAlloc& al, bool children) {
     using G = Geo<S>;
     constexpr int HS = TreeGeo<S>::HS;
     uint64_t lw[G::NW];
@@ -71,9 +136,8 @@ __device__ __forceinline__ int make_block(BoardWave<S>& bw, const BoardState<S>&
         for (int k = 0; k < G::NW; ++k) lw[k] = 0;
     }
     const int nchild = children ? (npts > 0 ? npts : 1) : 0;          // environment.py:121-129: pass only if alone
-    const int blk = free_slot;
-    if (blk + HS + nchild > cap) return -1;
-    free_slot = blk + HS + nchild;
+    const int blk = tree_alloc(d, al, HS + nchild);
+    if (blk < 0) return -1;
     const int lane = bw.lane;
     if (lane == 0) {
         BlockHdr<S> h;
@@ -102,7 +166,7 @@ __device__ __forceinline__ int make_block(BoardWave<S>& bw, const BoardState<S>&
 // states == nullptr: empty boards (reset_root, self_play.py:595-598).  Otherwise the root of every masked game is the given
 // position (select_action, self_play.py:689-700) and unmasked slots are parked (they take no part in searches).
 template <int S>
-__global__ __launch_bounds__(64) void k_reset(EngineDev d, const uint8_t* mask, const BoardState<S>* states) {
+__global__ __launch_bounds__(64) void k_reset(EngineDev d, const uint8_t* mask, const BoardState<S>* states, int fresh_pool) {
     using G = Geo<S>;
     __shared__ WaveLds<S> lds;
     const int g = blockIdx.x;
@@ -115,26 +179,32 @@ __global__ __launch_bounds__(64) void k_reset(EngineDev d, const uint8_t* mask, 
     BoardWave<S> bw; bw.init(&lds);
     GameCtl c = d.ctl[g];                                             // cumulative statistics survive a reset
     if (c.error && lane_id() == 0) atomicSub(&d.counters[CNT_ERRORS], 1);   // CNT_ERRORS = games parked in error right now
-    c.cur = 0; c.free_slot = 0; c.n_target = 0; c.active = 0; c.n_paths = 0; c.need_eval = 0; c.root_row = 0;
+    // the old tree's chunks go back to the pool (fresh_pool: the ring was just rebuilt with every chunk in it, nothing to return)
+    if (!fresh_pool) pool_push(d, chunk_list(d, g, c.cur), c.n_chunks);
+    c.cur = 0; c.free_slot = 0; c.chunk_end = 0; c.n_chunks = 0; c.root = 0;
+    c.n_target = 0; c.active = 0; c.n_paths = 0; c.need_eval = 0; c.root_row = 0;
     c.finished = 0; c.error = 0; c.searching = 0; c.moves = 0;
-    NodeRec* arena = arena_of<S>(d.arena, g, 0, d.sc.arena_slots);
+    NodeRec* arena = d.arena;
+    TreeAlloc al; al.ids = chunk_list(d, g, 0); al.n_chunks = 0; al.free_slot = 0; al.chunk_end = 0;
     BoardState<S> st;
     if (states) st = states[g]; else state_reset(st);
     const bool over = st.terminated != 0;
     bw.load_colors(st.bb[0], st.bb[1]);
     bw.analyze();
-    int free_slot = 1;
-    int blk = make_block(bw, st, arena, free_slot, d.sc.arena_slots, !over);
+    const int root = tree_alloc(d, al, 1);
+    int blk = root < 0 ? -1 : make_block(bw, st, arena, d, al, !over);
     if (!over) encode_bits<S, 0>(bw, st, d.rules, bits_s, d.obs_bits + (size_t)g * d.sc.R * d.obs_words);      // the game's slot 0
     if (bw.lane == 0) {
         NodeRec r;                                                    // Node_V(0), self_play.py:596 / :691
         r.prior = 0.0; r.w = 0.f; r.var = 0.f; r.n = 0; r.pending = 0; r.block = blk; r.action = 0xFFFF; r.flags = 0; r.term = 0;
-        arena[0] = r;
-        c.cur = 0; c.free_slot = free_slot; c.need_eval = over ? 0 : 1; c.root_row = 0; c.error = blk < 0 ? 1 : 0;
+        if (root >= 0) arena[root] = r;
+        c.cur = 0; c.free_slot = al.free_slot; c.chunk_end = al.chunk_end; c.n_chunks = al.n_chunks; c.root = root < 0 ? 0 : root;
+        if (al.n_chunks * d.sc.chunk_slots > c.hw_slot) c.hw_slot = al.n_chunks * d.sc.chunk_slots;
+        c.need_eval = over ? 0 : 1; c.root_row = 0; c.error = blk < 0 ? 1 : 0;
         c.finished = over ? 1 : 0;
-        if (c.error) atomicAdd(&d.counters[CNT_ERRORS], 1);
+        if (c.error) { atomicAdd(&d.counters[CNT_ERRORS], 1); c.need_eval = 0; }
         d.ctl[g] = c;
-        if (!over) d.game_nslot[g] = 1;
+        if (!over && !c.error) d.game_nslot[g] = 1;
     }
 }
 
@@ -145,8 +215,9 @@ __global__ __launch_bounds__(64) void k_expand_roots(EngineDev d) {
     const int g = blockIdx.x, lane = lane_id();
     GameCtl* c = &d.ctl[g];
     if (!c->need_eval) return;
-    NodeRec* arena = arena_of<S>(d.arena, g, c->cur, d.sc.arena_slots);
-    const int blk = arena[0].block, row = d.game_off[g];              // the root was the game's only entry of the batch
+    NodeRec* arena = d.arena;
+    const int root = c->root;
+    const int blk = arena[root].block, row = d.game_off[g];           // the root was the game's only entry of the batch
     const int nchild = hdr_of<S>(arena, blk)->nchild;
     const float* pol = d.policy + (size_t)row * d.sc.A;
     const float val = d.value[row];
@@ -157,7 +228,7 @@ __global__ __launch_bounds__(64) void k_expand_roots(EngineDev d) {
         r->flags = F_PRIOR32;
     }
     __syncthreads();
-    if (lane == 0) { arena[0].flags |= F_OPEN; c->need_eval = 0; }
+    if (lane == 0) { arena[root].flags |= F_OPEN; c->need_eval = 0; }
 }
 
 // Dirichlet root noise (self_play.py:90-95): prior <- prior*(1-0.25) + noise*0.25, float32*float -> float32, + float64
@@ -167,8 +238,8 @@ __global__ __launch_bounds__(64) void k_noise(EngineDev d, const double* noise) 
     const int g = blockIdx.x, lane = lane_id();
     GameCtl* c = &d.ctl[g];
     if (c->finished || c->error) return;
-    NodeRec* arena = arena_of<S>(d.arena, g, c->cur, d.sc.arena_slots);
-    const int blk = arena[0].block;
+    NodeRec* arena = d.arena;
+    const int blk = arena[c->root].block;
     const int nchild = hdr_of<S>(arena, blk)->nchild;
     for (int i = lane; i < nchild; i += 64) {
         NodeRec* r = &arena[blk + HS + i];
@@ -184,8 +255,7 @@ __global__ __launch_bounds__(64) void k_begin(EngineDev d, int sims) {
     const int g = blockIdx.x;
     if (lane_id() != 0) return;
     GameCtl* c = &d.ctl[g];
-    NodeRec* arena = arena_of<S>(d.arena, g, c->cur, d.sc.arena_slots);
-    c->n_target = arena[0].n + sims;                                  // self_play.py:662-663
+    c->n_target = d.arena[c->root].n + sims;                          // self_play.py:662-663
     c->searching = (c->finished || c->error) ? 0 : 1;
     c->active = c->searching;
 }
@@ -205,13 +275,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
     __shared__ uint32_t bits_s[(13 * G::P + 31) / 32];
     if (lane == 0) { c->n_paths = 0; d.game_nslot[g] = 0; d.game_act[g] = 0; }
     if (!c->searching || c->error) return;           // a game in error (arena overflow) is parked, never retried
-    NodeRec* arena = arena_of<S>(d.arena, g, c->cur, sc.arena_slots);
-    if (arena[0].n >= c->n_target) { if (lane == 0) c->active = 0; return; }
+    NodeRec* arena = d.arena;
+    const int root = __builtin_amdgcn_readfirstlane(c->root);
+    if (arena[root].n >= c->n_target) { if (lane == 0) c->active = 0; return; }
     if (lane == 0) d.game_act[g] = 1;
     int nslot = 0;                                   // evaluation-batch entries this game has written in this wave
     BoardWave<S> bw; bw.init(&lds);
     WaveRng rng; rng.key = d.rng[g].key; rng.pos = d.rng[g].pos; rng.scratch = mt_scratch; rng.draws = 0;
-    int free_slot = c->free_slot;
+    // wave-uniform by construction: kept in scalar registers (the kernel runs at a 128-VGPR budget)
+    TreeAlloc al; al.ids = chunk_list(d, g, __builtin_amdgcn_readfirstlane(c->cur)); al.n_chunks = __builtin_amdgcn_readfirstlane(c->n_chunks);
+    al.free_slot = __builtin_amdgcn_readfirstlane(c->free_slot); al.chunk_end = __builtin_amdgcn_readfirstlane(c->chunk_end);
     int* paths = d.path_nodes + (size_t)g * sc.R * sc.maxd;
     int npaths = 0, err = 0;
     int leafs[8], rows[8];
@@ -220,9 +293,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
 
     for (int attempt = 0; attempt < 2 * sc.R && npaths < sc.R && !err; ++attempt) {    // self_play.py:616
         int* path = paths + npaths * sc.maxd;
-        int node = 0, depth = 0;
-        if (lane == 0) { path[0] = 0; path_s[0] = 0; }
-        NodeRec cur = arena[0];
+        int node = root, depth = 0;
+        if (lane == 0) { path[0] = root; path_s[0] = root; }
+        NodeRec cur = arena[root];
         int pblk = -1;                                                 // block of the leaf's parent (its header holds the parent's position)
         // ---- selection (self_play.py:623-627, :706-725) ----
         // A level is ONE dependent HBM round trip: the node's child count and, speculatively, its first 64 child records are
@@ -232,7 +305,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
             const int blk = cur.block;
             NodeRec ch[NPASS];
             const int i0 = blk + HS + lane;
-            if (i0 < sc.arena_slots) ch[0] = arena[i0];               // inside this game's arena whatever the child count is
+            if (i0 < sc.pool_slots) ch[0] = arena[i0];                // inside the pool whatever the child count is
             const int nchild = hdr_of<S>(arena, blk)->nchild;
             pblk = blk;
 #pragma unroll
@@ -307,12 +380,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
                 TG_ST(2);
                 continue;
             }
-            const bool fits = free_slot + HS + G::A <= sc.arena_slots;  // room for the largest possible block
-            if (!fits) { err |= 1; break; }
             bw.load_colors(st.bb[0], st.bb[1]);
             bw.analyze();
             TG_ST(3);
-            const int blk = make_block(bw, st, arena, free_slot, sc.arena_slots, true);
+            const int blk = make_block(bw, st, arena, d, al, true);
+            if (blk < 0) { err |= 1; break; }                         // the game's cap or the pool: parked, restarted by the host
             TG_ST(4);
             row = nslot++;                                             // the game's own next slot: no allocation, no atomic
             encode_bits<S, 1>(bw, st, d.rules, bits_s, d.obs_bits + ((size_t)g * sc.R + row) * d.obs_words);   // self_play.py:798
@@ -334,8 +406,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
     TG_ST_FLUSH();
     if (lane == 0) {
         d.game_nslot[g] = nslot;
-        c->n_paths = npaths; c->free_slot = free_slot; c->error |= err;
-        if (free_slot > c->hw_slot) c->hw_slot = free_slot;
+        c->n_paths = npaths; c->free_slot = al.free_slot; c->chunk_end = al.chunk_end; c->n_chunks = al.n_chunks; c->error |= err;
+        if (al.n_chunks * sc.chunk_slots > c->hw_slot) c->hw_slot = al.n_chunks * sc.chunk_slots;
         c->sims += sims; c->depth_sum += depth_sum; c->evals += evals; c->tie_draws += rng.draws; c->child_sum += child_sum;
         d.rng[g].pos = rng.pos;
         if (err) { atomicAdd(&d.counters[CNT_ERRORS], 1); c->searching = 0; c->active = 0; }
@@ -351,7 +423,7 @@ __global__ __launch_bounds__(64) void k_absorb(EngineDev d) {
     const SearchCfg& sc = d.sc;
     const int npaths = c->n_paths;
     if (npaths == 0) return;
-    NodeRec* arena = arena_of<S>(d.arena, g, c->cur, sc.arena_slots);
+    NodeRec* arena = d.arena;
     const int* paths = d.path_nodes + (size_t)g * sc.R * sc.maxd;
     unsigned long long sims = 0;
     for (int q = 0; q < npaths; ++q) {                                 // self_play.py:651-654
@@ -395,8 +467,9 @@ __global__ __launch_bounds__(64) void k_root_info(EngineDev d, int32_t* visits, 
     __shared__ WaveLds<S> lds;
     const int g = blockIdx.x, lane = lane_id();
     GameCtl* c = &d.ctl[g];
-    NodeRec* arena = arena_of<S>(d.arena, g, c->cur, d.sc.arena_slots);
-    const int blk = arena[0].block;
+    NodeRec* arena = d.arena;
+    const int root = c->root;
+    const int blk = arena[root].block;
     BlockHdr<S>* h = hdr_of<S>(arena, blk);
     const int nchild = h->nchild;
     if (visits) {
@@ -405,7 +478,7 @@ __global__ __launch_bounds__(64) void k_root_info(EngineDev d, int32_t* visits, 
         for (int i = lane; i < nchild; i += 64) { NodeRec r = arena[blk + HS + i]; visits[(size_t)g * G::A + r.action] = r.n; }
     }
     if (lane == 0) {
-        if (root_n) root_n[g] = arena[0].n;
+        if (root_n) root_n[g] = arena[root].n;
         if (player) player[g] = h->st.next_player;
         if (step) step[g] = h->st.step_count;
         if (nchild_out) nchild_out[g] = (c->finished || c->error) ? 0 : nchild;
@@ -428,15 +501,16 @@ __global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions
     constexpr int HS = TreeGeo<S>::HS, NPASS = TreeGeo<S>::NPASS;
     __shared__ WaveLds<S> lds;
     __shared__ uint32_t bits_s[(13 * G::P + 31) / 32];
+    __shared__ int fill_s[kMaxChunks], cstart_s[kMaxChunks];   // chunk k of the new tree: first slot, and where its copied blocks end
     const int g = blockIdx.x, lane = lane_id();
     GameCtl* c = &d.ctl[g];
     if (lane == 0) d.game_nslot[g] = 0;
     if (c->finished || c->error) { if (lane == 0) { done_out[g] = c->error ? 2 : 1; moves_out[g] = c->moves; } return; }
     const SearchCfg& sc = d.sc;
-    NodeRec* old = arena_of<S>(d.arena, g, c->cur, sc.arena_slots);
-    NodeRec* nw = arena_of<S>(d.arena, g, c->cur ^ 1, sc.arena_slots);
+    NodeRec* const pool = d.arena;
+    NodeRec* const old = pool; NodeRec* const nw = pool;               // (the old and the new tree live in the same pool)
     const int a = actions[g];
-    const int rblk = old[0].block;
+    const int rblk = old[c->root].block;
     const int nchild = hdr_of<S>(old, rblk)->nchild;
     int idx = -1;
 #pragma unroll
@@ -464,28 +538,53 @@ __global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions
     bool ok;
     const bool done = state_step(bw, st, a, d.rules, /*check=*/false, &ok);      // self_play.py:859
     NodeRec child = old[rblk + HS + idx];
-    int nfree = 1;
+    // the new tree grows in fresh chunks, recorded in the game's OTHER chunk-id list
+    TreeAlloc na; na.ids = chunk_list(d, g, c->cur ^ 1); na.n_chunks = 0; na.free_slot = 0; na.chunk_end = 0;
+    const int nroot = tree_alloc(d, na, 1);
+    if (nroot < 0) {                                                   // not one chunk left in the pool: the game is parked with its tree intact
+        if (lane == 0) { c->error |= 1; c->searching = 0; c->active = 0; done_out[g] = 2; moves_out[g] = c->moves; atomicAdd(&d.counters[CNT_ERRORS], 1); }
+        return;
+    }
+    if (lane == 0) cstart_s[0] = nroot;
+    int kept = 1;                                                      // slots of the new tree
     if (child.flags & F_OPEN) {
         // keep the subtree: breadth-first copy, block by block, fixing block pointers as we go.  The reference's tree lives
-        // in unbounded Python memory; here the copy stops at `sc.keep_slots` (the arena minus the room one full search
-        // can need), shallow blocks first: a node whose block no longer fits keeps its statistics but becomes an unexpanded
-        // leaf again (it is re-evaluated on its next visit).  Never happens unless the kept tree outgrows the arena (very
-        // peaked policies, many moves in a row); counted in GameCtl::truncs.
+        // in unbounded Python memory; here the copy stops at `sc.keep_slots` (the game's cap minus the room one full search
+        // can need) or when the pool has no chunk left, shallow blocks first: a node whose block no longer fits keeps its
+        // statistics but becomes an unexpanded leaf again (it is re-evaluated on its next visit).  Never happens unless the
+        // kept tree outgrows the cap (very peaked policies, many moves in a row) or the pool; counted in GameCtl::truncs.
+        // Copied blocks sit back to back inside each chunk of the new list, chunk after chunk: fill_s[k] = where chunk k's
+        // blocks end, which is what the scan below walks.
         int dropped = 0;
         auto copy_block = [&](int src) -> int {
             const int n = HS + hdr_of<S>(old, src)->nchild;
-            if (nfree + n > sc.keep_slots) { ++dropped; return -1; }
+            if (kept + n > sc.keep_slots) { ++dropped; return -1; }
+            const int before = na.n_chunks, fill_before = na.free_slot;
+            const int at = tree_alloc(d, na, n);
+            if (at < 0) { ++dropped; return -1; }
+            if (na.n_chunks != before && lane == 0) { fill_s[before - 1] = fill_before; cstart_s[before] = at; }
             const uint4* s4 = reinterpret_cast<const uint4*>(old + src);
-            uint4* d4 = reinterpret_cast<uint4*>(nw + nfree);
+            uint4* d4 = reinterpret_cast<uint4*>(nw + at);
             for (int i = lane; i < 2 * n; i += 64) d4[i] = s4[i];
-            const int at = nfree;
-            nfree += n;
+            kept += n;
             return at;
         };
-        int scan = copy_block(child.block);
-        child.block = scan;
+        const int first = copy_block(child.block);
+        child.block = first;
+        if (first < 0) child.flags &= (uint8_t)~(F_OPEN | F_PSEUDO);
         __syncthreads();
-        while (scan < nfree) {
+        // scan cursor: chunk sc_k of the new list, slot `scan`; the root record occupies the first slot of chunk 0
+        int sc_k = 0, scan = nroot + 1;
+        while (first >= 0) {
+            // end of the blocks of chunk sc_k: recorded when the allocator left it, else the allocator's bump pointer
+            __syncthreads();
+            const int fill = sc_k < na.n_chunks - 1 ? fill_s[sc_k] : na.free_slot;
+            if (scan >= fill) {
+                if (sc_k >= na.n_chunks - 1) break;                    // caught up with the allocator: every copied block was scanned
+                ++sc_k;
+                scan = cstart_s[sc_k];
+                continue;
+            }
             const int nc = hdr_of<S>(nw, scan)->nchild;
             for (int j0 = 0; j0 < nc; j0 += 64) {
                 const int i = j0 + lane;
@@ -504,23 +603,32 @@ __global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions
                 }
             }
             scan += HS + nc;
-            __syncthreads();
         }
-        if (lane == 0) { nw[0] = child; c->truncs += dropped; }
+        if (lane == 0) { nw[nroot] = child; c->truncs += dropped; }
     } else {
         // fresh root: it will be evaluated and expanded with raw priors (self_play.py:861-870).  The reference does
         // so even when the game just ended; that evaluation has no observable effect and is skipped here.
         if (!done) { bw.load_colors(st.bb[0], st.bb[1]); bw.analyze(); }
-        const int blk = make_block(bw, st, nw, nfree, sc.arena_slots, !done);
+        const int blk = make_block(bw, st, nw, d, na, !done);
+        if (blk < 0) {                                                 // pool exhausted: park the game (old tree intact), give the new chunk back
+            pool_push(d, na.ids, na.n_chunks);
+            if (lane == 0) { c->error |= 1; c->searching = 0; c->active = 0; done_out[g] = 2; moves_out[g] = c->moves; atomicAdd(&d.counters[CNT_ERRORS], 1); }
+            return;
+        }
         child.block = blk; child.term = 0; child.flags &= (uint8_t)~F_PSEUDO;
-        if (lane == 0) nw[0] = child;
+        if (lane == 0) nw[nroot] = child;
         if (!done) {
             encode_bits<S, 2>(bw, st, d.rules, bits_s, d.obs_bits + (size_t)g * sc.R * d.obs_words);  // the game's slot 0
             if (lane == 0) { c->need_eval = 1; c->root_row = 0; d.game_nslot[g] = 1; }
         }
     }
+    __syncthreads();
+    // the old tree's chunks go back to the pool (poppable after k_pool_publish)
+    pool_push(d, chunk_list(d, g, c->cur), c->n_chunks);
     if (lane == 0) {
-        c->cur ^= 1; c->free_slot = nfree; c->finished = done ? 1 : 0; c->searching = 0; c->active = 0; c->moves = t + 1;
+        c->cur ^= 1; c->free_slot = na.free_slot; c->chunk_end = na.chunk_end; c->n_chunks = na.n_chunks; c->root = nroot;
+        if (na.n_chunks * sc.chunk_slots > c->hw_slot) c->hw_slot = na.n_chunks * sc.chunk_slots;
+        c->finished = done ? 1 : 0; c->searching = 0; c->active = 0; c->moves = t + 1;
         done_out[g] = done ? 1 : 0; moves_out[g] = t + 1;
     }
 }
@@ -542,9 +650,9 @@ __global__ __launch_bounds__(64) void k_harvest(EngineDev d, const int32_t* slot
     const size_t base = (size_t)off[f];
     GameCtl* c = &d.ctl[g];
     const int n = c->moves < d.hist_T ? c->moves : d.hist_T;
-    NodeRec* arena = arena_of<S>(d.arena, g, c->cur, d.sc.arena_slots);
+    NodeRec* arena = d.arena;
     BoardWave<S> bw; bw.init(&lds);
-    BoardState<S> st = hdr_of<S>(arena, arena[0].block)->st;
+    BoardState<S> st = hdr_of<S>(arena, arena[c->root].block)->st;
     uint8_t owner[G::NW];
     const float raw = tromp_taylor(bw, st, owner);
     const float sc = raw - d.rules.komi;                               // go_env.cc:129
@@ -578,8 +686,8 @@ __global__ __launch_bounds__(64) void k_root_states(EngineDev d, BoardState<S>* 
     const int g = blockIdx.x;
     if (lane_id() != 0) return;
     GameCtl* c = &d.ctl[g];
-    NodeRec* arena = arena_of<S>(d.arena, g, c->cur, d.sc.arena_slots);
-    out[g] = hdr_of<S>(arena, arena[0].block)->st;
+    NodeRec* arena = d.arena;
+    out[g] = hdr_of<S>(arena, arena[c->root].block)->st;
 }
 
 template <int S>
@@ -588,9 +696,9 @@ __global__ __launch_bounds__(64) void k_final(EngineDev d, float* score, float* 
     __shared__ WaveLds<S> lds;
     const int g = blockIdx.x, lane = lane_id();
     GameCtl* c = &d.ctl[g];
-    NodeRec* arena = arena_of<S>(d.arena, g, c->cur, d.sc.arena_slots);
+    NodeRec* arena = d.arena;
     BoardWave<S> bw; bw.init(&lds);
-    BoardState<S> st = hdr_of<S>(arena, arena[0].block)->st;
+    BoardState<S> st = hdr_of<S>(arena, arena[c->root].block)->st;
     uint8_t owner[G::NW];
     const float raw = tromp_taylor(bw, st, owner);
     const float sc = raw - d.rules.komi;
@@ -699,6 +807,14 @@ template <class F> void parallel_games(int n, F f) {
 
 extern "C" {
 
+// Default provision of the tree pool, slots per game on average: the per-game cap is (4*sims + 256) largest blocks, a game's tree
+// averages well under half of it (DESIGN.md 3 "Pool sizing": measured fill), and the sub-tree k_play keeps comes out of the same
+// slack before the old tree is returned.
+long long tg_default_pool_slots(int board_size, int num_simulation) {
+    const int A = board_size * board_size + 1, HS = board_size == 9 ? 2 : 4;
+    return (2LL * num_simulation + 128) * (HS + A);
+}
+
 int tg_engine_create(tg_ctx* ctx) {
     const tg_config& cfg = ctx->cfg;
     if (cfg.parallel_readouts < 1 || cfg.parallel_readouts > 8) TG_FAIL(ctx, TG_ERR_ARG, "parallel_readouts must be 1..8");
@@ -713,15 +829,33 @@ int tg_engine_create(tg_ctx* ctx) {
     sc.c1f = (float)cfg.c_puct1; sc.c2f = (float)cfg.c_puct2; sc.A = A;
     sc.maxd = ((cfg.max_step + 2 + 63) / 64) * 64;
     if (sc.maxd > kMaxPath) TG_FAIL(ctx, TG_ERR_ARG, "max_step too large for the path buffer (at most 510)");
-    long long slots = cfg.arena_slots > 0 ? cfg.arena_slots : (4LL * cfg.num_simulation + 256) * (HS + A);   // 3x truncated kept sub-trees in 0.2 % of the game-moves of full-length games
+    // per-game cap: most slots one game's tree may hold (3x the simulations truncated kept sub-trees in 0.2 % of the game-moves of
+    // full-length games); what bounds the SUM over the games is the pool below
+    long long slots = cfg.arena_slots > 0 ? cfg.arena_slots : (4LL * cfg.num_simulation + 256) * (HS + A);
     if (slots < 4LL * (HS + A) || slots > 0x3fffffffLL) TG_FAIL(ctx, TG_ERR_ARG, "arena_slots out of range");
     sc.arena_slots = (int)slots;
     // room a full search can need: one block per evaluated leaf, at most num_simulation + R of them per move
     const long long headroom = ((long long)cfg.num_simulation + R + 1) * (HS + A);
     sc.keep_slots = (int)(slots - headroom > 1 + HS + A ? slots - headroom : 1 + HS + A);
+    // chunk pool: chunks of 1024 slots (32 KB) at 9x9, 4096 (128 KB) at 19x19 -- a dozen largest blocks, so the tail a block
+    // leaves unused when it does not fit the current chunk is a few per cent; a game owns at least one chunk
+    sc.chunk_slots = ctx->S == 9 ? 1024 : 4096;
+    sc.max_chunks = (int)((slots + sc.chunk_slots - 1) / sc.chunk_slots) + 1;
+    if (sc.max_chunks > kMaxChunks) TG_FAIL(ctx, TG_ERR_ARG, "arena_slots too large for the chunk table (at most 2047 chunks per game)");
+    // pool size: cfg.pool_slots slots per game ON AVERAGE (0: default_pool_slots below), at least two chunks per game and one
+    // largest tree
+    long long per_game = cfg.pool_slots > 0 ? cfg.pool_slots : tg_default_pool_slots(ctx->S, cfg.num_simulation);
+    long long pool_chunks = ((long long)G * per_game + sc.chunk_slots - 1) / sc.chunk_slots;
+    if (pool_chunks < 2LL * G + sc.max_chunks) pool_chunks = 2LL * G + sc.max_chunks;
+    if (pool_chunks * sc.chunk_slots > 0x7fffffffLL)
+        TG_FAIL(ctx, TG_ERR_ARG, "tree pool larger than 2^31 slots (64 GiB): lower pool_slots or n_games");
+    sc.pool_chunks = (int)pool_chunks; sc.pool_slots = (int)(pool_chunks * sc.chunk_slots);
     e->dev.rules = ctx->rules;
-    size_t arena_bytes = (size_t)G * 2 * (size_t)slots * sizeof(NodeRec);
+    size_t arena_bytes = (size_t)sc.pool_slots * sizeof(NodeRec);
     TG_HIP(ctx, hipMalloc((void**)&e->dev.arena, arena_bytes));
+    TG_HIP(ctx, hipMalloc((void**)&e->dev.ring, sizeof(int32_t) * (size_t)sc.pool_chunks));
+    TG_HIP(ctx, hipMalloc((void**)&e->dev.pool, sizeof(PoolCtl)));
+    TG_HIP(ctx, hipMalloc((void**)&e->dev.chunk_ids, sizeof(int32_t) * (size_t)G * 2 * sc.max_chunks));
     TG_HIP(ctx, hipMalloc((void**)&e->dev.ctl, sizeof(GameCtl) * G));
     TG_HIP(ctx, hipMemsetAsync(e->dev.ctl, 0, sizeof(GameCtl) * G, ctx->stream));
     TG_HIP(ctx, hipMalloc((void**)&e->dev.rng, sizeof(tg_mt19937) * G));
@@ -761,6 +895,8 @@ int tg_engine_create(tg_ctx* ctx) {
     e->h_noise.resize((size_t)G * A);
     e->h_nchild.resize(G);
     e->arena_bytes = arena_bytes;
+    hipLaunchKernelGGL(k_pool_init, dim3(64), dim3(256), 0, ctx->stream, e->dev);
+    TG_HIP(ctx, hipGetLastError());
     TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (g_trace_launch) {                                             // where every engine buffer lives: a fault address can be placed
         const EngineDev& v = e->dev;
@@ -782,7 +918,7 @@ int tg_engine_create(tg_ctx* ctx) {
 void tg_engine_destroy(tg_ctx* ctx) {
     Engine* e = ctx->eng;
     if (!e) return;
-    void* ptrs[] = {e->dev.arena, e->dev.ctl, e->dev.rng, e->dev.path_nodes, e->dev.path_len, e->dev.path_row, e->dev.row_slot,
+    void* ptrs[] = {e->dev.arena, e->dev.ring, e->dev.pool, e->dev.chunk_ids, e->dev.ctl, e->dev.rng, e->dev.path_nodes, e->dev.path_len, e->dev.path_row, e->dev.row_slot,
                     e->dev.obs_bits, e->dev.game_nslot, e->dev.game_off, e->dev.game_act, e->dev.policy, e->dev.value, e->dev.counters, e->d_noise, e->d_i32, e->d_f32, e->d_u8,
                     e->d_fin, e->dev.hist_obs, e->dev.hist_cnt, e->dev.hist_pl};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -815,9 +951,14 @@ int tg_sp_reset(tg_ctx* ctx, const uint32_t* seeds, const uint8_t* mask) {
         d_mask = e->d_u8;
     }
     if (g_trace_launch) { fprintf(stderr, "[tg %ld] k_reset<%d> grid %d (masked %d)\n", ++g_trace_seq, ctx->S, G, mask ? 1 : 0); fflush(stderr); }
-    if (ctx->S == 9) hipLaunchKernelGGL(k_reset<9>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<9>*)nullptr);
-    else hipLaunchKernelGGL(k_reset<19>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<19>*)nullptr);
+    // every game at once: the ring is rebuilt with all chunks free and no game returns anything; a masked reset returns the
+    // restarted games' chunks (poppable after the publish below)
+    const int fresh = mask ? 0 : 1;
+    if (fresh) { hipLaunchKernelGGL(k_pool_init, dim3(64), dim3(256), 0, ctx->stream, e->dev); TG_HIP(ctx, hipGetLastError()); }
+    if (ctx->S == 9) hipLaunchKernelGGL(k_reset<9>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<9>*)nullptr, fresh);
+    else hipLaunchKernelGGL(k_reset<19>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<19>*)nullptr, fresh);
     TG_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_pool_publish, dim3(1), dim3(1), 0, ctx->stream, e->dev);
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, ctx->stream, e->dev, e->R, 0);
     TG_HIP(ctx, hipGetLastError());
     e->batch_kind = BATCH_ROOTS; e->batch_ready = false;
@@ -840,9 +981,10 @@ int tg_sp_reset_from(tg_ctx* ctx, const void* states, const uint8_t* mask) {
     if (mask) { TG_HIP(ctx, hipMemcpyAsync(e->d_u8, mask, G, hipMemcpyHostToDevice, ctx->stream)); d_mask = e->d_u8; }
     for (int g = 0; g < G; ++g) if (!mask || mask[g]) e->h_moves[g] = 0;
     e->fin_slot.clear(); e->fin_off.clear(); e->fin_positions = 0;
-    if (ctx->S == 9) hipLaunchKernelGGL(k_reset<9>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<9>*)ctx->env_in.p);
-    else hipLaunchKernelGGL(k_reset<19>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<19>*)ctx->env_in.p);
+    if (ctx->S == 9) hipLaunchKernelGGL(k_reset<9>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<9>*)ctx->env_in.p, 0);
+    else hipLaunchKernelGGL(k_reset<19>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<19>*)ctx->env_in.p, 0);
     TG_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_pool_publish, dim3(1), dim3(1), 0, ctx->stream, e->dev);
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, ctx->stream, e->dev, e->R, 0);
     TG_HIP(ctx, hipGetLastError());
     int32_t cnt[CNT_N];
@@ -1078,6 +1220,7 @@ int tg_sp_play(tg_ctx* ctx, const int32_t* actions, uint8_t* done) {
     int32_t* d_moves = e->d_i32 + G;
     std::vector<int32_t> prev = e->h_moves;
     TG_LAUNCH(ctx, k_play, G, e->dev, (const int32_t*)d_act, e->d_u8, d_moves);
+    hipLaunchKernelGGL(k_pool_publish, dim3(1), dim3(1), 0, ctx->stream, e->dev);      // the old trees' chunks are poppable from here on
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, ctx->stream, e->dev, e->R, 0);
     TG_HIP(ctx, hipGetLastError());
     TG_HIP(ctx, hipMemcpyAsync(done, e->d_u8, G, hipMemcpyDeviceToHost, ctx->stream));
@@ -1196,10 +1339,26 @@ int tg_sp_stats(tg_ctx* ctx, uint64_t* sims, uint64_t* evals, uint64_t* depth_su
     uint64_t s = 0, ev = 0, ds = 0, td = 0; int32_t er = 0, ms = 0;
     for (const GameCtl& c : h) {
         s += c.sims; ev += c.evals; ds += c.depth_sum; td += c.tie_draws;
-        er += c.error ? 1 : 0; ms = c.hw_slot > ms ? c.hw_slot : ms; ms = c.free_slot > ms ? c.free_slot : ms;   // a true high-water, not the current fill
+        er += c.error ? 1 : 0; ms = c.hw_slot > ms ? c.hw_slot : ms;   // a true high-water (chunks x chunk size), not the current fill
     }
     if (sims) *sims = s; if (evals) *evals = ev; if (depth_sum) *depth_sum = ds; if (tie_draws) *tie_draws = td;
     if (errors) *errors = er; if (max_slots) *max_slots = ms;
+    return TG_OK;
+}
+
+int tg_sp_pool_stats(tg_ctx* ctx, uint64_t* pool_slots, uint64_t* high_water_slots, uint64_t* in_use_slots, uint64_t* exhausted) {
+    NEED_ENGINE(ctx);
+    Engine* e = ctx->eng;
+    PoolCtl pc;
+    TG_HIP(ctx, hipMemcpyAsync(&pc, e->dev.pool, sizeof(pc), hipMemcpyDeviceToHost, ctx->stream));
+    TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const SearchCfg& sc = e->dev.sc;
+    const unsigned long long fr = pc.tail - pc.head;                   // free right now (everything pushed so far included)
+    unsigned long long mn = pc.min_free; const unsigned long long vis_free = pc.visible - pc.head; if (vis_free < mn) mn = vis_free;
+    if (pool_slots) *pool_slots = (uint64_t)sc.pool_slots;
+    if (high_water_slots) *high_water_slots = (uint64_t)((unsigned long long)sc.pool_chunks - mn) * sc.chunk_slots;
+    if (in_use_slots) *in_use_slots = (uint64_t)((unsigned long long)sc.pool_chunks - fr) * sc.chunk_slots;
+    if (exhausted) *exhausted = pc.exhausted;
     return TG_OK;
 }
 

@@ -2436,7 +2436,9 @@ int fill_weight_set(tg_ctx* ctx, Net* n, int k, const float* blob, hipStream_t s
     return TG_OK;
 }
 
-// A completed asynchronous refresh becomes the live set: called at the top of every forward pass and of every load.
+// A completed asynchronous refresh becomes the live set.  Called at boundaries only -- tg_sp_begin_move (tg_net_adopt_ready), every
+// stand-alone tg_net_predict, tg_net_load_poll, and at the top of every load -- never from forward(): a host that drives
+// tg_sp_collect / tg_net_forward / tg_sp_absorb itself adopts a refresh through tg_net_load_poll (include/transgo_hip.h).
 int adopt_pending(tg_ctx* ctx, Net* n, bool wait) {
     if (!n->pending) return TG_OK;
     if (wait) TG_HIP(ctx, hipEventSynchronize(n->loaded));
@@ -2568,8 +2570,9 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
 }
 
 // The refresh that never stalls a search: the blob is copied to pinned memory, uploaded and re-staged into the
-// retired weight set on a side stream while the context's stream keeps searching on the live set; the first forward pass that
-// finds the upload complete switches over.  Needs a network already loaded with the same architecture (else: synchronous).
+// retired weight set on a side stream while the context's stream keeps searching on the live set; the switch happens at the next
+// move boundary (tg_sp_begin_move), stand-alone tg_net_predict or tg_net_load_poll that finds the upload complete -- never inside a
+// search.  Needs a network already loaded with the same architecture (else: synchronous).
 int tg_net_load_async(tg_ctx* ctx, const char* arch_c, const float* blob, size_t n_floats) {
     if (!ctx || !blob || !arch_c) return TG_ERR_ARG;
     Net* n = ctx->eng ? ctx->eng->net : nullptr;

@@ -1,11 +1,16 @@
 // tree_dev.h -- device data structures + wave primitives of the batched WP_MCTS (self_play.py:51-95, :575-875).
 //
-// Layout in HBM.  Each game owns two half-arenas of 32-byte slots (the tree is compacted from one half into the other
-// when the root advances, so nothing is ever freed individually).  Slot 0 of the live half is the root record.  An
+// Layout in HBM (round 4).  ONE pool of 32-byte slots serves every game of the context, cut into chunks of SearchCfg::chunk_slots
+// slots; a game's tree lives in the chunks listed in its chunk-id list and grows by taking a chunk off the pool's free ring when
+// its current one is full (tree_alloc, engine.hip).  The pool is provisioned for the POPULATION of games, not for the worst game
+// times the number of games (rounds 1-3: two fixed half-arenas per game, 41 GB at BASELINE configs[1] for trees that fill a third
+// of it on average).  Node and block references are GLOBAL slot indices into the pool, so the hot kernels never translate
+// anything; GameCtl::root is the root record.  When the root advances (k_play) the kept sub-tree is copied breadth-first into
+// fresh chunks and the old tree's chunks go back to the ring, so nothing is ever freed piecemeal.  An
 // expanded (or pseudo-expanded) node owns a *block*: HS header slots holding its board state, followed by one
 // NodeRec per legal action in ascending action order (pass last) -- the iteration order of the reference's
-// `children` dict (self_play.py:603, :635).  Selection therefore reads one contiguous, fully coalesced run of
-// nchild*32 B per tree level; a wave's 64 lanes each take one child.
+// `children` dict (self_play.py:603, :635) -- contiguous inside one chunk.  Selection therefore reads one contiguous, fully
+// coalesced run of nchild*32 B per tree level; a wave's 64 lanes each take one child.
 #pragma once
 #include "board_dev.h"
 #include "../../include/transgo_hip.h"
@@ -40,9 +45,21 @@ template <int S> struct TreeGeo {
 };
 static_assert(sizeof(BlockHdr<9>) == 64 && sizeof(BlockHdr<19>) == 128, "header slots");
 
+// The free ring of the chunk pool.  head / tail count pops / pushes since creation (64-bit: never wrap); entry k of the ring is
+// ring[k % pool_chunks].  Chunks pushed by a kernel become poppable when k_pool_publish has run behind it (`visible`): a pop never
+// reads a ring entry that another workgroup of the same launch may still be writing.
+struct PoolCtl {
+    unsigned long long head, tail, visible;
+    unsigned long long min_free;     // fewest free chunks seen at a publish point (pool high-water = pool_chunks - min_free)
+    unsigned long long exhausted;    // pops that found the ring empty (the game is then parked in error 1 / its kept sub-tree truncated)
+};
+
 struct GameCtl {
-    int32_t cur;          // live half arena (0/1)
-    int32_t free_slot;    // next unused slot in the live half
+    int32_t cur;          // which of the game's two chunk-id lists holds the live tree (0/1; the other one is filled by k_play)
+    int32_t free_slot;    // next unused slot (global index) in the chunk the live tree is growing in
+    int32_t chunk_end;    // end of that chunk
+    int32_t n_chunks;     // chunks the live tree owns
+    int32_t root;         // global slot of the root record
     int32_t n_target;     // root visit target of the current move (self_play.py:662-663)
     int32_t active;       // still below target in this move
     int32_t n_paths;      // paths collected by the wave in flight
@@ -52,7 +69,7 @@ struct GameCtl {
     int32_t error;        // sticky: 1 arena overflow, 2 depth overflow, 4 bad action
     int32_t searching;    // begin_move issued
     int32_t moves;        // moves played in this game = entries of its device-side record (self_play.py:917-926)
-    int32_t hw_slot;      // largest free_slot this slot has reached (high-water of its half arena, cumulative like the counters below)
+    int32_t hw_slot;      // most slots (chunks x chunk_slots) a tree of this game has held (cumulative like the counters below)
     unsigned long long sims;        // completed backups (terminal ones included)
     unsigned long long evals;       // leaves sent to the evaluator
     unsigned long long depth_sum;   // sum of selection depths
@@ -66,8 +83,12 @@ struct SearchCfg {
     int wu;             // wu_loss
     double c1, c2;      // c_puct1, c_puct2
     float c1f, c2f;     // their float32 roundings (weak Python scalars next to float32 operands)
-    int arena_slots;    // per half
+    int arena_slots;    // most slots ONE game's tree may hold (per-game cap; the pool is what bounds the sum)
     int keep_slots;     // most slots a re-rooted tree may keep (arena_slots minus the room of one full search)
+    int chunk_slots;    // slots per chunk (>= the largest block)
+    int max_chunks;     // entries of a game's chunk-id list = chunks its tree may own
+    int pool_chunks;    // chunks in the pool
+    int pool_slots;     // pool_chunks * chunk_slots (< 2^31: slot indices are int32)
     int maxd;           // path capacity
     int A;
 };

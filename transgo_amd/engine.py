@@ -100,13 +100,14 @@ def choose_moves_batch(visits, steps, u, live, selfplay=True):
 class SelfPlayEngine:
     def __init__(self, n_games, board_size=9, num_simulation=210, parallel_readouts=4, c_puct1=3, c_puct2=0.05,
                  wu_loss=2, komi=7.5, max_step=120, encode_dim=10, net_blocks=6, net_filters=128, arena_slots=0,
-                 device=0, evaluator=None, net_precision="f32", record_games=True):
+                 device=0, evaluator=None, net_precision="f32", record_games=True, pool_slots=0):
         cfg = _lib.default_config()
         cfg.record_games = 1 if record_games else 0       # per-move records in HBM for tg_sp_harvest (self-play); evaluation matches need none
         cfg.net_precision = {"f32": 0, "f16": 1, "f16r": 2, "f32x3": 3}[net_precision]
         cfg.board_size, cfg.encode_dim, cfg.max_step, cfg.komi = board_size, encode_dim, max_step, komi
         cfg.n_games, cfg.num_simulation, cfg.parallel_readouts, cfg.wu_loss = n_games, num_simulation, parallel_readouts, wu_loss
         cfg.c_puct1, cfg.c_puct2, cfg.arena_slots = c_puct1, c_puct2, arena_slots
+        cfg.pool_slots = pool_slots                       # tree memory: slots per game ON AVERAGE in the pool all games share (0 = default)
         cfg.net_blocks, cfg.net_filters, cfg.device = net_blocks, net_filters, device
         self.ctx = _lib.Context(cfg)
         self.G, self.S, self.P, self.A, self.C = n_games, board_size, board_size ** 2, board_size ** 2 + 1, encode_dim
@@ -293,9 +294,17 @@ class SelfPlayEngine:
         self.ctx.call("tg_sp_tree_truncations", ctypes.byref(tr))
         out = dict(sims=v[0].value, evals=v[1].value, depth_sum=v[2].value, tie_draws=v[3].value, errors=e.value,
                    max_slots=m.value, truncated_blocks=tr.value, fp16_overflows=0)
+        out.update(self.pool_stats())
         if self.evaluator is None:
             out["fp16_overflows"] = self.net_range()["fp16_overflows"]
         return out
+
+    def pool_stats(self):
+        """tg_sp_pool_stats: the tree pool all games share -- its size, the most that was in use at once, what is in use now (32-byte
+        slots) and how often a game found it empty."""
+        v = [ctypes.c_uint64() for _ in range(4)]
+        self.ctx.call("tg_sp_pool_stats", *[ctypes.byref(x) for x in v])
+        return dict(pool_slots=v[0].value, pool_high_water=v[1].value, pool_in_use=v[2].value, pool_exhausted=v[3].value)
 
     def net_range(self):
         """tg_net_range: sticky count of output tiles in which a value beyond +-65504 was rounded to fp16 (net_precision 1-3; 0 = every

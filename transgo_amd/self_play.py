@@ -78,7 +78,7 @@ class BatchedSelfPlay:
     lists (observations, visit counts, players; self_play.py:917-926) lives in HBM inside the engine; a finished game leaves
     it as a `records.Harvest` batch -- in device memory when the consumer is on the GPU too."""
 
-    def __init__(self, config, n_games, device=0, rank=0, world=1, evaluator=None, arena_slots=0, seed_fn=None):
+    def __init__(self, config, n_games, device=0, rank=0, world=1, evaluator=None, arena_slots=0, seed_fn=None, pool_slots=0):
         self.config, self.G, self.rank, self.world = config, n_games, rank, world
         self.S = config.board_size
         self.filters = getattr(config, "num_features", 128)
@@ -92,6 +92,7 @@ class BatchedSelfPlay:
             wu_loss=config.wu_loss, komi=config.komi, max_step=config.max_step,
             encode_dim=config.encode_state_channels, net_blocks=self.blocks, net_filters=self.filters,
             arena_slots=arena_slots, device=device, evaluator=evaluator,
+            pool_slots=pool_slots or getattr(config, "tree_pool_slots", 0),
             net_precision=getattr(config, "inference_dtype", "f32"))
         self.seed_fn = seed_fn
         self.games_started = np.zeros(n_games, np.int64)
@@ -222,41 +223,62 @@ class GroupedSelfPlay:
     seeds as the ungrouped engine), and a network row does not depend on which rows share its batch
     (tests/test_gpu_selfplay.py::test_grouped_selfplay_plays_the_same_games)."""
 
-    def __init__(self, config, n_games, groups=2, device=0, rank=0, world=1, arena_slots=0):
+    def __init__(self, config, n_games, groups=2, device=0, rank=0, world=1, arena_slots=0, pool_slots=0):
         assert groups >= 1 and n_games % groups == 0, "games must divide evenly over the groups"
         self.config, self.G, self.K, self.rank, self.world = config, n_games, groups, rank, world
         per = n_games // groups
-        self.parts = [BatchedSelfPlay(config, per, device=device, rank=rank, world=world, arena_slots=arena_slots,
+        self.parts = [BatchedSelfPlay(config, per, device=device, rank=rank, world=world, arena_slots=arena_slots, pool_slots=pool_slots,
                                       seed_fn=(lambda g, r, k=k: default_seed(rank, world, n_games, k * per + g, r)))
                       for k in range(groups)]
         self.S, self.device = config.board_size, device
+        self._pool = None
 
     def _each(self, fn):
-        """fn(part) for every group on its own host thread (the library releases the GIL inside its calls)."""
+        """fn(part) for every group on its own host thread (the library releases the GIL inside its calls).  The K threads are a
+        persistent pool (one worker per group, created once: a move is one submit per group, not K thread starts).  A group that
+        fails must not leave the job half alive: in a multi-rank actor loop the other ranks would sit in the next collective until
+        the process-group timeout, so once every group's call has returned, a failure aborts the process group (peers then fail
+        fast instead of waiting) before the first exception is re-raised."""
         if self.K == 1:
             return [fn(self.parts[0])]
-        import threading
-        out, err = [None] * self.K, [None] * self.K
-
-        def run(k):
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=self.K, thread_name_prefix="transgo-group")
+        futs = [self._pool.submit(fn, p) for p in self.parts]
+        out, first = [], None
+        for f in futs:
             try:
-                out[k] = fn(self.parts[k])
-            except BaseException as e:          # re-raised in the caller's thread
-                err[k] = e
-        th = [threading.Thread(target=run, args=(k,)) for k in range(self.K)]
-        [t.start() for t in th]; [t.join() for t in th]
-        for e in err:
-            if e is not None:
-                raise e
+                out.append(f.result())
+            except BaseException as e:          # re-raised in the caller's thread, after every group has returned
+                out.append(None)
+                first = first or e
+        if first is not None:
+            self._abort_peers()
+            raise first
         return out
 
+    @staticmethod
+    def _abort_peers():
+        """A failed group on this rank: tear the process group down so that peers blocked in a collective error out now."""
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.destroy_process_group()
+        except Exception:
+            pass
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+
     def set_weights(self, state_dict):
-        for p in self.parts:
-            p.set_weights(state_dict)
+        return self._each(lambda p: p.set_weights(state_dict))[0]
 
     def set_weights_blob(self, blob, background=False):
-        for p in self.parts:
-            p.set_weights_blob(blob, background)
+        # the K uploads go out together, one per group thread (each device -> device load ends with a host-blocking stream wait:
+        # issued one after the other they would serialise K waits)
+        self._each(lambda p: p.set_weights_blob(blob, background))
 
     # what the actor loop reads off its worker (SelfPlay.continuous_self_play)
     @property

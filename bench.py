@@ -386,8 +386,15 @@ def main(argv=None):
     import torch
     import torch.distributed as dist
     backend = os.environ.get("TRANSGO_DIST_BACKEND", "nccl")        # "gloo": rehearsal of the N>1 path with several ranks on one GPU
+    # TRANSGO_BENCH_STANDIN=1 (with gloo): a CPU rehearsal of the N-rank control flow -- launcher, process group, per-move exchange,
+    # reductions, the line -- with tests/bench_standin.py in place of the HIP engine: no GPU is touched and nothing it prints is a
+    # measurement (the line says so in `data`).  How BASELINE configs[2]/[4]'s world of 8 is rehearsed where 8 GPU processes cannot run.
+    standin = os.environ.get("TRANSGO_BENCH_STANDIN", "0") == "1"
+    if standin and backend == "nccl":
+        raise SystemExit("TRANSGO_BENCH_STANDIN=1 is a CPU rehearsal: set TRANSGO_DIST_BACKEND=gloo")
     dev = torch.device("cuda", local if backend == "nccl" else 0)
-    torch.cuda.set_device(dev)
+    if not standin:
+        torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         pg_timeout = datetime.timedelta(seconds=float(os.environ.get("TRANSGO_PG_TIMEOUT", "1800")))
@@ -397,7 +404,8 @@ def main(argv=None):
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=pg_timeout)
     cdev = dev if backend == "nccl" else torch.device("cpu")          # where collective payloads live
     # what the process group really is: answered from the group, not from the arguments
-    props = torch.cuda.get_device_properties(dev)
+    from types import SimpleNamespace
+    props = SimpleNamespace(name="stand-in (no GPU)") if standin else torch.cuda.get_device_properties(dev)
     me = {"rank": rank, "device": int(dev.index), "name": props.name, "pid": os.getpid(),
           "bus": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", ""))}
     if world > 1:
@@ -428,7 +436,11 @@ def main(argv=None):
         # the shipped MainNetwork's policies are peaked even at random init: at the default arena 0.5 % of the game-moves lose kept
         # sub-tree blocks at re-rooting (counted in truncated_tree_blocks; DESIGN.md 3 "Sizing") -- twice the default holds them all
         a.arena_slots = 2 * (4 * a.sims + 256) * ((2 if S == 9 else 4) + S * S + 1)
-    if a.groups > 1:
+    if standin:
+        from tests.bench_standin import StandInReplay, StandInSelfPlay
+        sp = StandInSelfPlay(cfg, a.games, rank=rank, world=world)
+        parts = [sp]
+    elif a.groups > 1:
         sp = GroupedSelfPlay(cfg, a.games, groups=a.groups, device=gpu, rank=rank, world=world, arena_slots=a.arena_slots,
                              pool_slots=a.pool_slots)
         parts = sp.parts
@@ -441,10 +453,11 @@ def main(argv=None):
         sp.set_weights(model.random_weights(S, 10, a.filters, a.blocks, seed=1234))
     # rank 0 owns the replay store (north_star: "RCCL gather of (s, pi, z) tuples into the replay buffer"); sized for every
     # position the run can produce
-    mem = DeviceReplayMemory(cfg, capacity_positions=max(1024, world * a.games * (a.steps + a.warmup + 2)), device=gpu) \
-        if rank == 0 else None
+    mem = None
+    if rank == 0:
+        mem = StandInReplay() if standin else DeviceReplayMemory(cfg, capacity_positions=max(1024, world * a.games * (a.steps + a.warmup + 2)), device=gpu)
     sp.start()
-    period = a.stagger if a.stagger >= 0 else (cfg.max_step if S == 9 else 0)
+    period = 0 if standin else (a.stagger if a.stagger >= 0 else (cfg.max_step if S == 9 else 0))
     t_st = time.perf_counter()
     if period > 1:
         if a.groups > 1:
@@ -456,7 +469,8 @@ def main(argv=None):
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not standin:
+            torch.cuda.synchronize()
 
     tally = {"games": 0, "positions": 0}
 
@@ -553,12 +567,24 @@ def main(argv=None):
 
     if rank == 0:
         # HBM bytes per launch of the dominant kernel come from PMC passes (separate rocprofv3 runs, committed under profiles/);
-        # they only describe the configuration they were collected on
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", {"f32": "r3_pmc_traffic.json", "f32x3": "r3_pmc_f32x3.json"}.get(a.dtype, "r1_pmc_traffic_f16.json"))
-        if a.dtype in ("f32", "f16", "f32x3") and os.path.exists(tfile) and (S, a.filters, a.games, a.network) == (9, 128, 4096, "tower"):
+        # they describe one configuration AND one build: the file records the hash of net.hip it was collected on, and a figure
+        # from another build is not reported (traffic = null, the note says why) instead of going stale silently
+        traffic, tnote = None, "PMC traffic was collected for the 9x9 / 128-filter / 4096-board tower workload only"
+        tname = {"f32": "pmc_traffic.json", "f32x3": "pmc_f32x3.json"}.get(a.dtype)
+        tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if tname and f.endswith("_" + tname)) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+        if tfiles and (S, a.filters, a.games, a.network) == (9, 128, 4096, "tower"):
+            import hashlib
+            tfile = os.path.join(ROOT, "profiles", tfiles[-1])                # the latest round's
             with open(tfile) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch_mean")
+                pj = json.load(f)
+            src = os.path.join(ROOT, "transgo_amd", "csrc", "net.hip")
+            now = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16] if os.path.exists(src) else None
+            if pj.get("net_hip_sha16") and pj["net_hip_sha16"] == now:
+                traffic = pj.get("hbm_bytes_per_launch_mean")
+                tnote = f"HBM bytes per full-batch launch, FETCH_SIZE x2 + WRITE_SIZE (profiles/{tfiles[-1]}, collected on this build of net.hip)"
+            else:
+                tnote = (f"profiles/{tfiles[-1]} was collected on another build of net.hip ({pj.get('net_hip_sha16')} vs {now}): not reported; "
+                         "re-collect with scripts/collect_profiles.sh")
         value = sims_all / dt
         conv_tflops = (fl.value / (ms.value * 1e-3)) / 1e12 if ms.value > 0 else 0.0
         fpl = flops_per_leaf(S, 10, a.filters, a.blocks) if a.network == "tower" else None
@@ -575,7 +601,8 @@ def main(argv=None):
         line = {
             "metric": "MCTS simulations/sec", "value": round(value, 1), "unit": "sims/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
+            "data": "stand-in engine (CPU rehearsal of the N-rank control flow: NOT a measurement)" if standin else "synthetic",
             "games_per_hour": round(games_stored / dt * 3600.0, 1),
             "ranks": ranks,
             "config": {"workload": f"{S}x{S} Go self-play, {a.sims} sims/move, {net_name}, "
@@ -591,8 +618,7 @@ def main(argv=None):
                                    f"{period - 1} plies); {period - 1} untimed moves with 16-simulation searches, {stagger_s:.1f} s") if period > 1 else "none: all boards start together"},
             "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": round(peak, 1),
                          "unit": "TFLOP/s", "frac": round(conv_tflops / peak, 4), "traffic": traffic,
-                         "traffic_note": (f"HBM bytes per full-batch launch, FETCH_SIZE x2 + WRITE_SIZE (profiles/{os.path.basename(tfile)})"
-                                          if traffic is not None else "PMC traffic was collected for the 9x9 / 128-filter / 4096-board workload only"),
+                         "traffic_note": tnote,
                          "peak_note": ("dense fp16 MFMA peak / 3: every F->F conv runs three partial products (w_hi a_hi, w_hi a_lo, w_lo a_hi; "
                                        "w_lo a_lo, 2^-22 of a product, is dropped) on the fp16 MFMA; achieved counts the conv's 2*9*F*F FLOP "
                                        "per row once") if a.dtype == "f32x3" else None,

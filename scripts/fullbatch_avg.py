@@ -8,7 +8,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0]
     if k.startswith("k_conv3x3_sg") or k.startswith("k_conv3x3_h2"):
         per[k].append((int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"]), float(r["End_Timestamp"]) - float(r["Start_Timestamp"])))
-out = {"source": "the run of the kernel-stats file beside this one (rocprofv3 --kernel-trace --stats on `python3 bench.py --steps 20 --warmup 5 "
+out = {"source": "the run of the kernel-stats file beside this one (rocprofv3 --kernel-trace --stats on `python3 bench.py --no-launcher --steps 20 --warmup 5 "
                  "--no-cpu-baseline`), per-dispatch trace: launches of the F->F conv whose grid is within 5 % of the largest (full leaf "
                  "batches; the --stats averages also contain the root-evaluation launches of a few dozen rows)", "kernels": {}}
 for k, v in sorted(per.items()):

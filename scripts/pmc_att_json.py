@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise the PMC passes of scripts/collect_pmc_att_r3.sh into profiles/r3_pmc_attention_x3.json: MFMA pipe busy, waiting share and
+"""Summarise the PMC passes of scripts/collect_profiles.sh att into profiles/r3_pmc_attention_x3.json: MFMA pipe busy, waiting share and
 HBM traffic of k_attention_x3<9,128,PRO> (full-batch launches of `bench.py --network transgo --dtype f32x3`)."""
 import collections, csv, glob, json, re, statistics, sys
 ROOT = sys.argv[1] if len(sys.argv) > 1 else "/tmp/prof_att_raw"
@@ -18,8 +18,8 @@ def load(d):
 
 
 sq, fe, wr = load(f"{ROOT}/sq"), load(f"{ROOT}/fetch"), load(f"{ROOT}/write")
-out = {"source": "rocprofv3 --kernel-trace --pmc ... (separate passes: SQ counters, FETCH_SIZE, WRITE_SIZE; scripts/collect_pmc_att_r3.sh) on "
-                 "`python3 bench.py --network transgo --dtype f32x3 --steps 1 --warmup 1 --no-cpu-baseline` (9x9, 400 sims, MainNetwork 128, 4096 "
+out = {"source": "rocprofv3 --kernel-trace --pmc ... (separate passes: SQ counters, FETCH_SIZE, WRITE_SIZE; scripts/collect_profiles.sh att) on "
+                 "`python3 bench.py --no-launcher --no-cpu-baseline --network transgo --dtype f32x3 --steps 1 --warmup 1` (9x9, 400 sims, MainNetwork 128, 4096 "
                  "boards); medians over the launches of ~16 k boards (duration within 15 % of the largest) of k_attention_x3<9,128,PRO>",
        "correction": "FETCH_SIZE doubled (gfx950: MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact; unit KB.  MFMA pipe busy = "
                      "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs)",

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/collect_profiles_r3.sh -> profiles/rN_pmc_traffic.json.
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/collect_profiles.sh -> profiles/rN_pmc_traffic.json.
 usage: pmc_json.py [gpurun_out/prof_r2] [out.json]"""
 import collections, csv, glob, json, statistics, sys
 
@@ -20,7 +20,7 @@ def load(d, counter):
 
 
 fe, wr = load(ROOT + "/fetch", "FETCH_SIZE"), load(ROOT + "/write", "WRITE_SIZE")
-out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, scripts/collect_profiles_r3.sh) on `python3 bench.py "
+out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, scripts/collect_profiles.sh) on `python3 bench.py "
                  "--steps 1 --warmup 1 --no-cpu-baseline`; medians over the launches of the last (timed) step -- for the conv kernel over its "
                  "full-batch launches (grid within 5 % of the largest)",
        "correction": "FETCH_SIZE doubled (gfx950 tallies 128-B requests as 64 B: MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact; counter unit KB",
@@ -56,6 +56,9 @@ tc, ta = out["kernels"]["k_collect<9>"], out["kernels"]["k_absorb<9>"]
 out["tree_stage"] = {"hbm_bytes_per_wave": tc["hbm_bytes_per_launch"] + ta["hbm_bytes_per_launch"],
                      "note": "k_collect + k_absorb per search wave (4096 games x up to 4 read-outs, ~16 k simulations); bench.py prices the same wave at "
                              "bytes_per_sim x sims (roofline_tree); the 32-B-record reads are outside the FETCH_SIZE calibration, so treat the ratio as indicative"}
+import hashlib, os
+_src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "transgo_amd", "csrc", "net.hip")
+out["net_hip_sha16"] = hashlib.sha256(open(_src, "rb").read()).hexdigest()[:16]      # bench.py reports `traffic` only for this build
 json.dump(out, open(OUT, "w"), indent=1)
 for k, v in out["kernels"].items():
     if "conv3x3_sg" in k:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise the split-precision passes of scripts/collect_profiles_r3.sh (gpurun_out/prof_r3/x3_*) into profiles/r3_pmc_f32x3.json:
+"""Summarise the split-precision passes of scripts/collect_profiles.sh (gpurun_out/prof_r3/x3_*) into profiles/r3_pmc_f32x3.json:
 MFMA pipe busy, wave-cycle waiting share and HBM traffic of k_conv3x3_h2<9,256,128,EPI,false,X2> at BASELINE configs[1]'s shape."""
 import collections, csv, glob, json, re, statistics, sys
 ROOT = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r3"
@@ -20,8 +20,8 @@ def load(d):
 
 sq, fe, wr = load(f"{ROOT}/x3_sq"), load(f"{ROOT}/x3_fetch"), load(f"{ROOT}/x3_write")
 line = json.loads(open(f"{ROOT}/line_x3_c2.json").read())
-out = {"source": "rocprofv3 --kernel-trace --pmc ... (separate passes: SQ counters, FETCH_SIZE, WRITE_SIZE; scripts/collect_profiles_r3.sh) on "
-                 "`python3 bench.py --dtype f32x3 --steps 1 --warmup 1 --no-cpu-baseline` (9x9, 400 sims, 6x128, 4096 boards); medians over the "
+out = {"source": "rocprofv3 --kernel-trace --pmc ... (separate passes: SQ counters, FETCH_SIZE, WRITE_SIZE; scripts/collect_profiles.sh) on "
+                 "`python3 bench.py --no-launcher --no-cpu-baseline --dtype f32x3 --steps 1 --warmup 1` (9x9, 400 sims, 6x128, 4096 boards); medians over the "
                  "full-batch launches (grid within 5 % of the largest) of k_conv3x3_h2<9,256,128,EPI,false,X2>",
        "correction": "FETCH_SIZE doubled (gfx950: MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact; unit KB.  MFMA pipe busy = "
                      "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs)", "kernels": {}}
@@ -44,5 +44,8 @@ ks = list(out["kernels"].values())
 out["hbm_bytes_per_launch_mean"] = sum(v["hbm_bytes_per_launch"] for v in ks) / max(1, len(ks))
 out["bench_line_unprofiled"] = {"value_sims_per_s": line["value"], "conv_tflops_effective": line["roofline"]["achieved"], "frac_of_fp16_peak_over_3": line["roofline"]["frac"],
                                 "avg_launch_ms": line["roofline"]["avg_launch_ms"], "net_tflops_end_to_end": line["extra"]["net_tflops_end_to_end"]}
+import hashlib, os
+_src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "transgo_amd", "csrc", "net.hip")
+out["net_hip_sha16"] = hashlib.sha256(open(_src, "rb").read()).hexdigest()[:16]      # bench.py reports `traffic` only for this build
 json.dump(out, open(OUT, "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])

@@ -87,6 +87,9 @@ def test_bench_one_gpu_line_carries_the_secondary_legs():
     assert x3["dtype"] == "f32x3" and "fp16 MFMA peak / 3" in x3["roofline"]["peak_note"] and x3["fp16_overflows"] == 0
     assert mn["dtype"] == "f32" and "MainNetwork" in mn["workload"] and mn["roofline"]["peak"] == line["roofline"]["peak"]
     assert line["extra"]["fp16_overflows"] == 0
+    tp = line["extra"]["tree_pool"]                                          # one shared tree pool per context: size, fill, never empty
+    assert tp["slots"] > 0 and 0 < tp["high_water_slots"] <= tp["slots"] and tp["ran_empty"] == 0
+    assert x3["tree_pool"]["ran_empty"] == 0 and mn["tree_pool"]["ran_empty"] == 0
 
 
 def test_bench_refuses_rccl_ranks_that_share_a_gpu():

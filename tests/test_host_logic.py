@@ -529,3 +529,39 @@ def test_actor_loop_peer_death_is_a_nonzero_exit_not_a_hang():
     assert all(not p.is_alive() for p in ps), "a rank is still hanging"
     assert ps[1].exitcode == 3 and ps[0].exitcode not in (0, None)
     assert time.time() - t0 < 80
+
+
+def test_bench_launcher_world8_rehearsal_with_the_stand_in_engine():
+    """BASELINE configs[2]/[4] are world 8, and this pool cannot run eight GPU processes on one card: the whole N-rank control flow of
+    `bench.py --gpus 8` -- the launcher's eight fresh ranks, the gloo group, the per-move finished-game exchange (default transport),
+    the reductions, per-rank figures, ONE line -- runs on the CPU with tests/bench_standin.py in place of the HIP engine."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "TRANSGO_GATHER")}
+    env.update(TRANSGO_BENCH_STANDIN="1", TRANSGO_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + "--gpus 8 --games 64 --steps 3 --warmup 1 --no-cpu-baseline".split(),
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert "NOT a measurement" in line["data"] and line["n_gpus"] == 8 and line["scaling"] == "weak"
+    rk = line["ranks"]
+    assert rk["world"] == 8 and rk["backend"] == "gloo" and rk["launcher"] == "bench.py" and rk["seeds_disjoint"] is True
+    assert len({d["pid"] for d in rk["devices"]}) == 8 and sorted(d["rank"] for d in rk["devices"]) == list(range(8))
+    assert rk["transport"].startswith("all_gather")
+    pr = rk["per_rank"]
+    assert [p["rank"] for p in pr] == list(range(8)) and all(p["games_finished"] == 3 * (1 + p["rank"] % 3) for p in pr)
+    sg = line["selfplay_games"]
+    assert sg["finished_and_stored"] == sg["finished_all_ranks"] == sum(p["games_finished"] for p in pr)     # every rank's games reached rank 0
+    assert sg["positions_stored"] == sum(p["games_finished"] * (2 + p["rank"] % 4) for p in pr)
+    assert abs(sum(p["sims"] for p in pr) / (line["ms_per_step"] * line["steps"] * 1e-3) - line["value"]) <= 1e-3 * line["value"]
+    # the same job over the opt-in exact-length send/recv stores the same games
+    env["TRANSGO_GATHER"] = "p2p"
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + "--gpus 8 --games 64 --steps 3 --warmup 1 --no-cpu-baseline".split(),
+                        cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    l2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][0])
+    assert "isend/irecv" in l2["ranks"]["transport"] and l2["selfplay_games"]["positions_stored"] == sg["positions_stored"]

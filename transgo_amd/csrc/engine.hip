@@ -34,6 +34,10 @@ __device__ unsigned long long g_stamp[16], g_stamp2[8];
 #endif
 
 // ---- device helpers -------------------------------------------------------------------------------------------------------
+#ifndef TG_PENDING_ATOMIC
+#define TG_PENDING_ATOMIC 0                           // 1: WU-UCT counters as no-return atomics -- measured 1-2 % SLOWER on the tree stage than the
+                                                     // read-modify-write (0.207 vs 0.203 ms per wave, profiles/r4_ab_tree_counters.txt): not the default
+#endif
 constexpr int kMaxPath = 512;                        // longest selection path kept in LDS (>= SearchCfg::maxd, checked at create)
 constexpr int kMaxChunks = 2048;                     // most chunks one game's tree may own (>= SearchCfg::max_chunks, checked at create)
 
@@ -52,17 +56,15 @@ template <int S> __device__ __forceinline__ BlockHdr<S>* hdr_of(NodeRec* arena, 
 
 // ---- chunk pool (tree_dev.h) -------------------------------------------------------------------------------------------
 // One chunk id off the free ring, or -1 when no chunk is visible (lane 0 calls it).  Only entries published before this launch
-// are taken, so the entry read here was written by an earlier kernel.
+// are taken, so the entry read here was written by an earlier kernel.  ONE fetch-add per pop: a ticket below `visible` is a chunk,
+// a ticket at or beyond it is a failure (the pool is dry) and k_pool_publish takes the overshoot back before it publishes more.
+// (A compare-and-swap loop here cost 0.7 ms per search wave: ~1300 games ask for a chunk in the same wave, and every failed
+// exchange retries against the same address.)
 __device__ __forceinline__ int pool_pop(const EngineDev& d) {
     PoolCtl* pc = d.pool;
     const unsigned long long vis = pc->visible;
-    unsigned long long h = __hip_atomic_load(&pc->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (;;) {
-        if (h >= vis) { atomicAdd(&pc->exhausted, 1ull); return -1; }
-        const unsigned long long old = atomicCAS(&pc->head, h, h + 1);
-        if (old == h) break;
-        h = old;
-    }
+    const unsigned long long h = atomicAdd(&pc->head, 1ull);
+    if (h >= vis) { atomicAdd(&pc->exhausted, 1ull); return -1; }
     return d.ring[h % (unsigned long long)d.sc.pool_chunks];
 }
 // n chunk ids back onto the ring (whole wave; poppable once k_pool_publish has run behind this kernel)
@@ -75,39 +77,51 @@ __device__ __forceinline__ void pool_push(const EngineDev& d, const int32_t* ids
     base = ((unsigned long long)hi << 32) | lo;
     for (int i = lane; i < n; i += 64) d.ring[(base + i) % (unsigned long long)d.sc.pool_chunks] = ids[i];
 }
-__global__ void k_pool_init(EngineDev d) {
+// every chunk free (creation, and a reset of all games); the statistics survive a reset
+__global__ void k_pool_init(EngineDev d, int first) {
     const int n = d.sc.pool_chunks;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d.ring[i] = i;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        PoolCtl pc; pc.head = 0; pc.tail = pc.visible = (unsigned long long)n; pc.min_free = (unsigned long long)n; pc.exhausted = 0;
+        PoolCtl pc; pc.head = 0; pc.tail = pc.visible = (unsigned long long)n;
+        pc.min_free = first ? (unsigned long long)n : d.pool->min_free; pc.exhausted = first ? 0 : d.pool->exhausted;
         *d.pool = pc;
     }
 }
 // behind every kernel that pushes (k_play, k_reset): what it pushed becomes poppable; the fill just before is the cycle's peak
 __global__ void k_pool_publish(EngineDev d) {
     PoolCtl* pc = d.pool;
+    if (pc->head > pc->visible) pc->head = pc->visible;             // tickets drawn on a dry pool were failures, not pops
     const unsigned long long fr = pc->visible - pc->head;
     if (fr < pc->min_free) pc->min_free = fr;
     pc->visible = pc->tail;
 }
 
 // A tree under construction / growing: the chunk-id list it records its chunks in and the bump pointer inside the newest chunk.
+// The room left in that chunk follows from the pointer alone (chunks are a power of two and a fresh chunk is used at once, so a
+// pointer ON a chunk boundary always means "full" -- or "no chunk yet"): the hot kernel carries ONE register of allocator state,
+// as it did with the fixed arenas.  n_chunks lives in a register while a tree is built (k_play, k_reset) and in GameCtl while it
+// grows (k_collect: `ctl` set, touched on the rare new-chunk path only).
 struct TreeAlloc {
-    int32_t* ids; int n_chunks, free_slot, chunk_end;
+    int32_t* ids; int n_chunks, free_slot; GameCtl* ctl;
 };
 // n contiguous slots (n <= chunk_slots) for the tree, from its current chunk or a fresh one off the pool; -1 = the game's cap
 // (max_chunks) or the pool is exhausted.  Called by the whole wave; every lane gets the same answer.
 __device__ __forceinline__ int tree_alloc(const EngineDev& d, TreeAlloc& al, int n) {
-    if (al.free_slot + n > al.chunk_end) {
-        if (al.n_chunks >= d.sc.max_chunks) return -1;
+    const int room = (-al.free_slot) & (d.sc.chunk_slots - 1);
+    if (n > room) {
         int id = -1;
-        if (lane_id() == 0) id = pool_pop(d);
+        if (lane_id() == 0) {
+            const int have = al.ctl ? al.ctl->n_chunks : al.n_chunks;
+            if (have < d.sc.max_chunks) id = pool_pop(d);
+            if (id >= 0) {
+                al.ids[have] = id;
+                if (al.ctl) { al.ctl->n_chunks = have + 1; const int hw = (have + 1) * d.sc.chunk_slots; if (hw > al.ctl->hw_slot) al.ctl->hw_slot = hw; }
+            }
+        }
         id = __builtin_amdgcn_readfirstlane(id);
         if (id < 0) return -1;
-        if (lane_id() == 0) al.ids[al.n_chunks] = id;
         ++al.n_chunks;
         al.free_slot = id * d.sc.chunk_slots;
-        al.chunk_end = al.free_slot + d.sc.chunk_slots;
     }
     const int at = al.free_slot;
     al.free_slot = __builtin_amdgcn_readfirstlane(al.free_slot + n);
@@ -163,10 +177,22 @@ __device__ __forceinline__ int make_block(BoardWave<S>& bw, const BoardState<S>&
 
 // ---- kernels ---------------------------------------------------------------------------------------------------------------
 
+// Before a masked reset: the restarted games hand their chunks back (visible to k_reset's pops after k_pool_publish -- a pool that
+// ran completely dry must still be able to restart the games it parked).
+__global__ __launch_bounds__(64) void k_release(EngineDev d, const uint8_t* mask) {
+    const int g = blockIdx.x;
+    if (mask && !mask[g]) return;
+    GameCtl* c = &d.ctl[g];
+    const int n = c->n_chunks;
+    pool_push(d, chunk_list(d, g, c->cur), n);
+    __syncthreads();
+    if (lane_id() == 0) { c->n_chunks = 0; c->free_slot = 0; }
+}
+
 // states == nullptr: empty boards (reset_root, self_play.py:595-598).  Otherwise the root of every masked game is the given
 // position (select_action, self_play.py:689-700) and unmasked slots are parked (they take no part in searches).
 template <int S>
-__global__ __launch_bounds__(64) void k_reset(EngineDev d, const uint8_t* mask, const BoardState<S>* states, int fresh_pool) {
+__global__ __launch_bounds__(64) void k_reset(EngineDev d, const uint8_t* mask, const BoardState<S>* states) {
     using G = Geo<S>;
     __shared__ WaveLds<S> lds;
     const int g = blockIdx.x;
@@ -179,13 +205,12 @@ __global__ __launch_bounds__(64) void k_reset(EngineDev d, const uint8_t* mask, 
     BoardWave<S> bw; bw.init(&lds);
     GameCtl c = d.ctl[g];                                             // cumulative statistics survive a reset
     if (c.error && lane_id() == 0) atomicSub(&d.counters[CNT_ERRORS], 1);   // CNT_ERRORS = games parked in error right now
-    // the old tree's chunks go back to the pool (fresh_pool: the ring was just rebuilt with every chunk in it, nothing to return)
-    if (!fresh_pool) pool_push(d, chunk_list(d, g, c.cur), c.n_chunks);
-    c.cur = 0; c.free_slot = 0; c.chunk_end = 0; c.n_chunks = 0; c.root = 0;
+    // (the old tree's chunks went back to the pool in k_release, or the ring was just rebuilt with every chunk in it)
+    c.cur = 0; c.free_slot = 0; c.n_chunks = 0; c.root = 0;
     c.n_target = 0; c.active = 0; c.n_paths = 0; c.need_eval = 0; c.root_row = 0;
     c.finished = 0; c.error = 0; c.searching = 0; c.moves = 0;
     NodeRec* arena = d.arena;
-    TreeAlloc al; al.ids = chunk_list(d, g, 0); al.n_chunks = 0; al.free_slot = 0; al.chunk_end = 0;
+    TreeAlloc al; al.ids = chunk_list(d, g, 0); al.n_chunks = 0; al.free_slot = 0; al.ctl = nullptr;
     BoardState<S> st;
     if (states) st = states[g]; else state_reset(st);
     const bool over = st.terminated != 0;
@@ -198,7 +223,7 @@ __global__ __launch_bounds__(64) void k_reset(EngineDev d, const uint8_t* mask, 
         NodeRec r;                                                    // Node_V(0), self_play.py:596 / :691
         r.prior = 0.0; r.w = 0.f; r.var = 0.f; r.n = 0; r.pending = 0; r.block = blk; r.action = 0xFFFF; r.flags = 0; r.term = 0;
         if (root >= 0) arena[root] = r;
-        c.cur = 0; c.free_slot = al.free_slot; c.chunk_end = al.chunk_end; c.n_chunks = al.n_chunks; c.root = root < 0 ? 0 : root;
+        c.cur = 0; c.free_slot = al.free_slot; c.n_chunks = al.n_chunks; c.root = root < 0 ? 0 : root;
         if (al.n_chunks * d.sc.chunk_slots > c.hw_slot) c.hw_slot = al.n_chunks * d.sc.chunk_slots;
         c.need_eval = over ? 0 : 1; c.root_row = 0; c.error = blk < 0 ? 1 : 0;
         c.finished = over ? 1 : 0;
@@ -282,9 +307,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
     int nslot = 0;                                   // evaluation-batch entries this game has written in this wave
     BoardWave<S> bw; bw.init(&lds);
     WaveRng rng; rng.key = d.rng[g].key; rng.pos = d.rng[g].pos; rng.scratch = mt_scratch; rng.draws = 0;
-    // wave-uniform by construction: kept in scalar registers (the kernel runs at a 128-VGPR budget)
-    TreeAlloc al; al.ids = chunk_list(d, g, __builtin_amdgcn_readfirstlane(c->cur)); al.n_chunks = __builtin_amdgcn_readfirstlane(c->n_chunks);
-    al.free_slot = __builtin_amdgcn_readfirstlane(c->free_slot); al.chunk_end = __builtin_amdgcn_readfirstlane(c->chunk_end);
+    // one register of allocator state (wave-uniform: scalar); the chunk count stays in GameCtl (the kernel runs at a 128-VGPR budget)
+    TreeAlloc al; al.ids = chunk_list(d, g, __builtin_amdgcn_readfirstlane(c->cur)); al.n_chunks = 0; al.ctl = c;
+    al.free_slot = __builtin_amdgcn_readfirstlane(c->free_slot);
     int* paths = d.path_nodes + (size_t)g * sc.R * sc.maxd;
     int npaths = 0, err = 0;
     int leafs[8], rows[8];
@@ -391,13 +416,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
             TG_ST(5);
             if (lane == 0) {
                 arena[node].block = blk;
-                arena[node].flags |= F_PSEUDO;
+                arena[node].flags = (uint8_t)(cur.flags | F_PSEUDO);   // (`cur` is this node's record: a store, not a read-modify-write)
             }
             ++evals;
         }
         leafs[npaths] = node; rows[npaths] = row;
         __syncthreads();
-        for (int dd = lane; dd < len; dd += 64) arena[path_s[dd]].pending += sc.wu;    // self_play.py:767-770
+#if TG_PENDING_ATOMIC
+        for (int dd = lane; dd < len; dd += 64) atomicAdd(&arena[path_s[dd]].pending, sc.wu);    // self_play.py:767-770 (no-return atomic)
+#else
+        for (int dd = lane; dd < len; dd += 64) arena[path_s[dd]].pending += sc.wu;
+#endif
         if (lane == 0) { d.path_len[(size_t)g * sc.R + npaths] = len; d.path_row[(size_t)g * sc.R + npaths] = row; }
         __syncthreads();
         ++npaths;
@@ -406,8 +435,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
     TG_ST_FLUSH();
     if (lane == 0) {
         d.game_nslot[g] = nslot;
-        c->n_paths = npaths; c->free_slot = al.free_slot; c->chunk_end = al.chunk_end; c->n_chunks = al.n_chunks; c->error |= err;
-        if (al.n_chunks * sc.chunk_slots > c->hw_slot) c->hw_slot = al.n_chunks * sc.chunk_slots;
+        c->n_paths = npaths; c->free_slot = al.free_slot; c->error |= err;
         c->sims += sims; c->depth_sum += depth_sum; c->evals += evals; c->tie_draws += rng.draws; c->child_sum += child_sum;
         d.rng[g].pos = rng.pos;
         if (err) { atomicAdd(&d.counters[CNT_ERRORS], 1); c->searching = 0; c->active = 0; }
@@ -429,7 +457,12 @@ __global__ __launch_bounds__(64) void k_absorb(EngineDev d) {
     for (int q = 0; q < npaths; ++q) {                                 // self_play.py:651-654
         const int* path = paths + q * sc.maxd;
         const int len = d.path_len[(size_t)g * sc.R + q], row = d.game_off[g] + d.path_row[(size_t)g * sc.R + q];
-        for (int dd = lane; dd < len; dd += 64) arena[path[dd]].pending -= sc.wu;     // self_play.py:772-774
+        // (a no-return atomic: the read-modify-write it replaces was a dependent HBM round trip in front of everything below)
+#if TG_PENDING_ATOMIC
+        for (int dd = lane; dd < len; dd += 64) atomicSub(&arena[path[dd]].pending, sc.wu);     // self_play.py:772-774
+#else
+        for (int dd = lane; dd < len; dd += 64) arena[path[dd]].pending -= sc.wu;
+#endif
         __syncthreads();
         const int leaf = path[len - 1];
         NodeRec lr = arena[leaf];
@@ -539,7 +572,7 @@ __global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions
     const bool done = state_step(bw, st, a, d.rules, /*check=*/false, &ok);      // self_play.py:859
     NodeRec child = old[rblk + HS + idx];
     // the new tree grows in fresh chunks, recorded in the game's OTHER chunk-id list
-    TreeAlloc na; na.ids = chunk_list(d, g, c->cur ^ 1); na.n_chunks = 0; na.free_slot = 0; na.chunk_end = 0;
+    TreeAlloc na; na.ids = chunk_list(d, g, c->cur ^ 1); na.n_chunks = 0; na.free_slot = 0; na.ctl = nullptr;
     const int nroot = tree_alloc(d, na, 1);
     if (nroot < 0) {                                                   // not one chunk left in the pool: the game is parked with its tree intact
         if (lane == 0) { c->error |= 1; c->searching = 0; c->active = 0; done_out[g] = 2; moves_out[g] = c->moves; atomicAdd(&d.counters[CNT_ERRORS], 1); }
@@ -626,7 +659,7 @@ __global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions
     // the old tree's chunks go back to the pool (poppable after k_pool_publish)
     pool_push(d, chunk_list(d, g, c->cur), c->n_chunks);
     if (lane == 0) {
-        c->cur ^= 1; c->free_slot = na.free_slot; c->chunk_end = na.chunk_end; c->n_chunks = na.n_chunks; c->root = nroot;
+        c->cur ^= 1; c->free_slot = na.free_slot; c->n_chunks = na.n_chunks; c->root = nroot;
         if (na.n_chunks * sc.chunk_slots > c->hw_slot) c->hw_slot = na.n_chunks * sc.chunk_slots;
         c->finished = done ? 1 : 0; c->searching = 0; c->active = 0; c->moves = t + 1;
         done_out[g] = done ? 1 : 0; moves_out[g] = t + 1;
@@ -895,7 +928,7 @@ int tg_engine_create(tg_ctx* ctx) {
     e->h_noise.resize((size_t)G * A);
     e->h_nchild.resize(G);
     e->arena_bytes = arena_bytes;
-    hipLaunchKernelGGL(k_pool_init, dim3(64), dim3(256), 0, ctx->stream, e->dev);
+    hipLaunchKernelGGL(k_pool_init, dim3(64), dim3(256), 0, ctx->stream, e->dev, 1);
     TG_HIP(ctx, hipGetLastError());
     TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (g_trace_launch) {                                             // where every engine buffer lives: a fault address can be placed
@@ -953,12 +986,15 @@ int tg_sp_reset(tg_ctx* ctx, const uint32_t* seeds, const uint8_t* mask) {
     if (g_trace_launch) { fprintf(stderr, "[tg %ld] k_reset<%d> grid %d (masked %d)\n", ++g_trace_seq, ctx->S, G, mask ? 1 : 0); fflush(stderr); }
     // every game at once: the ring is rebuilt with all chunks free and no game returns anything; a masked reset returns the
     // restarted games' chunks (poppable after the publish below)
-    const int fresh = mask ? 0 : 1;
-    if (fresh) { hipLaunchKernelGGL(k_pool_init, dim3(64), dim3(256), 0, ctx->stream, e->dev); TG_HIP(ctx, hipGetLastError()); }
-    if (ctx->S == 9) hipLaunchKernelGGL(k_reset<9>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<9>*)nullptr, fresh);
-    else hipLaunchKernelGGL(k_reset<19>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<19>*)nullptr, fresh);
+    if (!mask) hipLaunchKernelGGL(k_pool_init, dim3(64), dim3(256), 0, ctx->stream, e->dev, 0);
+    else {
+        hipLaunchKernelGGL(k_release, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask);
+        hipLaunchKernelGGL(k_pool_publish, dim3(1), dim3(1), 0, ctx->stream, e->dev);
+    }
     TG_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_pool_publish, dim3(1), dim3(1), 0, ctx->stream, e->dev);
+    if (ctx->S == 9) hipLaunchKernelGGL(k_reset<9>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<9>*)nullptr);
+    else hipLaunchKernelGGL(k_reset<19>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<19>*)nullptr);
+    TG_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, ctx->stream, e->dev, e->R, 0);
     TG_HIP(ctx, hipGetLastError());
     e->batch_kind = BATCH_ROOTS; e->batch_ready = false;
@@ -981,10 +1017,13 @@ int tg_sp_reset_from(tg_ctx* ctx, const void* states, const uint8_t* mask) {
     if (mask) { TG_HIP(ctx, hipMemcpyAsync(e->d_u8, mask, G, hipMemcpyHostToDevice, ctx->stream)); d_mask = e->d_u8; }
     for (int g = 0; g < G; ++g) if (!mask || mask[g]) e->h_moves[g] = 0;
     e->fin_slot.clear(); e->fin_off.clear(); e->fin_positions = 0;
-    if (ctx->S == 9) hipLaunchKernelGGL(k_reset<9>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<9>*)ctx->env_in.p, 0);
-    else hipLaunchKernelGGL(k_reset<19>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<19>*)ctx->env_in.p, 0);
-    TG_HIP(ctx, hipGetLastError());
+    // (unmasked slots are parked by k_reset and keep the one chunk they own until their next reset)
+    hipLaunchKernelGGL(k_release, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask);
     hipLaunchKernelGGL(k_pool_publish, dim3(1), dim3(1), 0, ctx->stream, e->dev);
+    TG_HIP(ctx, hipGetLastError());
+    if (ctx->S == 9) hipLaunchKernelGGL(k_reset<9>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<9>*)ctx->env_in.p);
+    else hipLaunchKernelGGL(k_reset<19>, dim3(G), dim3(64), 0, ctx->stream, e->dev, (const uint8_t*)d_mask, (const BoardState<19>*)ctx->env_in.p);
+    TG_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, ctx->stream, e->dev, e->R, 0);
     TG_HIP(ctx, hipGetLastError());
     int32_t cnt[CNT_N];
@@ -1353,6 +1392,7 @@ int tg_sp_pool_stats(tg_ctx* ctx, uint64_t* pool_slots, uint64_t* high_water_slo
     TG_HIP(ctx, hipMemcpyAsync(&pc, e->dev.pool, sizeof(pc), hipMemcpyDeviceToHost, ctx->stream));
     TG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const SearchCfg& sc = e->dev.sc;
+    if (pc.head > pc.visible) pc.head = pc.visible;                    // (failed tickets on a dry pool, not yet taken back by a publish)
     const unsigned long long fr = pc.tail - pc.head;                   // free right now (everything pushed so far included)
     unsigned long long mn = pc.min_free; const unsigned long long vis_free = pc.visible - pc.head; if (vis_free < mn) mn = vis_free;
     if (pool_slots) *pool_slots = (uint64_t)sc.pool_slots;

@@ -1529,6 +1529,9 @@ __device__ unsigned long long g_att_stamp[32];
 #ifndef TG_ATT_TOUCH
 #define TG_ATT_TOUCH 1
 #endif
+#ifndef TG_ATT_RESID_PERM
+#define TG_ATT_RESID_PERM 1
+#endif
 template <int S, int F, bool PRO>
 __global__ __launch_bounds__(256, 1) void k_attention_x3(const float* __restrict__ xin, float* __restrict__ out, _Float16* __restrict__ out2,
                                                          const _Float16* __restrict__ wimg, const float* __restrict__ qb,
@@ -1570,7 +1573,8 @@ __global__ __launch_bounds__(256, 1) void k_attention_x3(const float* __restrict
     // every access: {first five tiles, last tile} x {8-channel column of the projection reads, 4-channel column of the D tiles}.
     constexpr int LASTR = P - 1 - (NT - 1) * 16;                                     // last valid row of the last tile
     const unsigned rowA = (unsigned)j * F * 4u, rowB = (unsigned)(j <= LASTR ? j : LASTR) * F * 4u;
-    const unsigned xoA = rowA + chx * 4u, xoB = rowB + chx * 4u, eoA = rowA + kq * 16u, eoB = rowB + kq * 16u;
+    const unsigned xoA = rowA + chx * 4u, xoB = rowB + chx * 4u, eoA = rowA + kq * 16u;
+    [[maybe_unused]] const unsigned eoB = rowB + kq * 16u;
     const unsigned hoA = ((unsigned)(kq >> 1) * M + j) * 16u + (kq & 1) * 8u;        // split chunk-major output, + t*256 per tile
     auto tile = [](const float* board, int t) { return board + t * 16 * F; };
     auto ld16 = [](const float* base, unsigned byte_off) { return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off); };
@@ -1750,15 +1754,35 @@ __global__ __launch_bounds__(256, 1) void k_attention_x3(const float* __restrict
             }
             TG_ASTAMP(2 + 4 * tm);
             __builtin_amdgcn_sched_barrier(0);
-            // the residual rows of column tile tm, D layout (row = channel ct*16 + kq*4 + r, column = position tm*16 + j): requested BEFORE
-            // the next block's rows (they are cache hits and must not queue behind loads that go to HBM)
+            // the residual rows of column tile tm, D layout (row = channel ct*16 + kq*4 + r, column = position tm*16 + j).
+            // TG_ATT_RESID_PERM (round 4, default): taken from the block's ROW registers, which hold exactly these values in the
+            // projection layout -- lane (j, kq') has channels g*16 + (kq' & 1)*8 .. +7 of row j, the lane pairs kq' and kq' + 2
+            // hold the same eight -- so lanes kq' < 2 offer their first four, lanes kq' >= 2 their last four, and destination
+            // (j, kq) pulls from (j, (kq >> 1) + 2*(kq & 1)): one ds_bpermute per register, no memory access at all.  (Round 3
+            // read them from memory again: meant to be cache hits on the lines the row loads had just fetched, they were the third
+            // trip to HBM -- the XCD's L2 turns over within a row block, profiles/r3_pmc_attention_x3.json: 2.19 GB fetched.)
             f32x4 xa[CT];
+#if TG_ATT_RESID_PERM
+            {
+                const int src = ((((kq >> 1) + 2 * (kq & 1)) << 4) + j) << 2;          // byte address of the source lane
+                const bool hi_half = kq >= 2;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    // (scalar copies: a bit_cast of a vector ELEMENT sends the whole vector through scratch)
+                    const float s0 = hi_half ? rv[ct][1][0] : rv[ct][0][0], s1 = hi_half ? rv[ct][1][1] : rv[ct][0][1];
+                    const float s2 = hi_half ? rv[ct][1][2] : rv[ct][0][2], s3 = hi_half ? rv[ct][1][3] : rv[ct][0][3];
+                    xa[ct] = f32x4{__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(s0))), __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(s1))),
+                                   __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(s2))), __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(s3)))};
+                }
+            }
+#else
             {
                 unsigned o = tm + 1 < NT ? eoA : eoB;
                 asm volatile("" : "+v"(o));
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) xa[ct] = ld16(tile(xb, tm), o + ct * 64);
             }
+#endif
             if (tm + 1 < NT) issue_rows(tm + 1);                                      // lands during the block's energy / output GEMMs
             __builtin_amdgcn_sched_barrier(0);                                       // (kept here: sunk to the block's end they are waited for at once)
 #pragma unroll

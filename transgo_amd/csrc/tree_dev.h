@@ -56,8 +56,7 @@ struct PoolCtl {
 
 struct GameCtl {
     int32_t cur;          // which of the game's two chunk-id lists holds the live tree (0/1; the other one is filled by k_play)
-    int32_t free_slot;    // next unused slot (global index) in the chunk the live tree is growing in
-    int32_t chunk_end;    // end of that chunk
+    int32_t free_slot;    // next unused slot (global index) in the chunk the live tree is growing in (on a chunk boundary = no room)
     int32_t n_chunks;     // chunks the live tree owns
     int32_t root;         // global slot of the root record
     int32_t n_target;     // root visit target of the current move (self_play.py:662-663)

@@ -297,6 +297,9 @@ def _result_line(txt):
 SECONDARY_LEGS = (
     ("f32x3", ["--dtype", "f32x3"], 10, 3),
     ("mainnetwork_f32", ["--network", "transgo", "--dtype", "f32"], 3, 1),
+    # the headline's own arithmetic with the boards as four independent groups on four HIP streams (same games bit for bit): the
+    # best exact-f32 rate of the build; not the headline because per-launch durations stop being exclusive (roofline.exclusive false)
+    ("f32_groups4", ["--groups", "4"], 8, 2),
 )
 
 
@@ -310,7 +313,8 @@ def _secondary_summary(line, wall_s):
             "net_tflops_end_to_end": ex.get("net_tflops_end_to_end"), "leaves_per_s": ex.get("leaves_per_s"),
             "tree_errors": ex.get("tree_errors"), "fp16_overflows": ex.get("fp16_overflows"),
             "truncated_tree_blocks": ex.get("truncated_tree_blocks"), "arena_high_water_slots": ex.get("arena_high_water_slots"),
-            "tree_pool": ex.get("tree_pool"),
+            "tree_pool": ex.get("tree_pool"), "groups_per_gpu": (line.get("config") or {}).get("groups_per_gpu"),
+            "roofline_exclusive": rf.get("exclusive"),
             "leg_wall_s": round(wall_s, 1)}
 
 

@@ -78,14 +78,15 @@ def test_bench_one_gpu_line_carries_the_secondary_legs():
     assert line["dtype"] == "f32" and line["n_gpus"] == 1 and "6-block x 128-filter tower" in line["config"]["workload"]
     assert line["ranks"]["launcher"] == "bench.py" and line["ranks"]["world"] == 1 and line["cpu_baseline"]["value"] > 0
     sec = line["secondary"]
-    x3, mn = sec["f32x3"], sec["mainnetwork_f32"]
-    for leg in (x3, mn):
+    x3, mn, g4 = sec["f32x3"], sec["mainnetwork_f32"], sec["f32_groups4"]
+    for leg in (x3, mn, g4):
         assert "error" not in leg, leg
         assert leg["value"] > 0 and leg["ms_per_step"] > 0 and leg["steps"] == 2 and leg["warmup"] == 1 and leg["tree_errors"] == 0
         assert leg["roofline"]["achieved"] > 0 and 0 < leg["roofline"]["frac"] <= 1 and leg["roofline"]["launches_not_timed"] == 0
         assert leg["ms_per_step"] * leg["steps"] * 1e-3 < leg["leg_wall_s"]
     assert x3["dtype"] == "f32x3" and "fp16 MFMA peak / 3" in x3["roofline"]["peak_note"] and x3["fp16_overflows"] == 0
     assert mn["dtype"] == "f32" and "MainNetwork" in mn["workload"] and mn["roofline"]["peak"] == line["roofline"]["peak"]
+    assert g4["dtype"] == "f32" and g4["groups_per_gpu"] == 4 and g4["roofline_exclusive"] is False and line["roofline"]["exclusive"] is True
     assert line["extra"]["fp16_overflows"] == 0
     tp = line["extra"]["tree_pool"]                                          # one shared tree pool per context: size, fill, never empty
     assert tp["slots"] > 0 and 0 < tp["high_water_slots"] <= tp["slots"] and tp["ran_empty"] == 0

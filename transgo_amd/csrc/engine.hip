@@ -38,8 +38,13 @@ __device__ unsigned long long g_stamp[16], g_stamp2[8];
 #define TG_PENDING_ATOMIC 0                           // 1: WU-UCT counters as no-return atomics -- measured 1-2 % SLOWER on the tree stage than the
                                                      // read-modify-write (0.207 vs 0.203 ms per wave, profiles/r4_ab_tree_counters.txt): not the default
 #endif
+#ifndef TG_POOL_PREFETCH
+#define TG_POOL_PREFETCH 1                            // k_collect pops the chunk a wave may need at its start (0: on demand; A/B builds)
+#endif
 constexpr int kMaxPath = 512;                        // longest selection path kept in LDS (>= SearchCfg::maxd, checked at create)
-constexpr int kMaxChunks = 2048;                     // most chunks one game's tree may own (>= SearchCfg::max_chunks, checked at create)
+// most chunks one game's tree may own (>= SearchCfg::max_chunks, checked at create).  k_play keeps two ints per chunk of the new tree
+// in LDS; at 9x9 all 4096 single-wave workgroups of a launch should be resident at once (16 per CU), so the table stays small there
+template <int S> struct ChunkCap { static constexpr int N = S == 9 ? 512 : 2048; };
 
 // The record lane `src` (wave-uniform) holds, for every lane.
 __device__ __forceinline__ NodeRec bcast_rec(const NodeRec& r, int src) {
@@ -60,9 +65,8 @@ template <int S> __device__ __forceinline__ BlockHdr<S>* hdr_of(NodeRec* arena, 
 // a ticket at or beyond it is a failure (the pool is dry) and k_pool_publish takes the overshoot back before it publishes more.
 // (A compare-and-swap loop here cost 0.7 ms per search wave: ~1300 games ask for a chunk in the same wave, and every failed
 // exchange retries against the same address.)
-__device__ __forceinline__ int pool_pop(const EngineDev& d) {
+__device__ __forceinline__ int pool_pop(const EngineDev& d, unsigned long long vis) {
     PoolCtl* pc = d.pool;
-    const unsigned long long vis = pc->visible;
     const unsigned long long h = atomicAdd(&pc->head, 1ull);
     if (h >= vis) { atomicAdd(&pc->exhausted, 1ull); return -1; }
     return d.ring[h % (unsigned long long)d.sc.pool_chunks];
@@ -98,11 +102,12 @@ __global__ void k_pool_publish(EngineDev d) {
 
 // A tree under construction / growing: the chunk-id list it records its chunks in and the bump pointer inside the newest chunk.
 // The room left in that chunk follows from the pointer alone (chunks are a power of two and a fresh chunk is used at once, so a
-// pointer ON a chunk boundary always means "full" -- or "no chunk yet"): the hot kernel carries ONE register of allocator state,
-// as it did with the fixed arenas.  n_chunks lives in a register while a tree is built (k_play, k_reset) and in GameCtl while it
-// grows (k_collect: `ctl` set, touched on the rare new-chunk path only).
+// pointer ON a chunk boundary always means "full" -- or "no chunk yet").  `ctl` set (k_collect): the chunk count and the game's
+// high-water are written through to GameCtl on the rare new-chunk path.
 struct TreeAlloc {
     int32_t* ids; int n_chunks, free_slot; GameCtl* ctl;
+    unsigned long long visible;      // PoolCtl::visible, read once at the top of the kernel (constant during a launch): off the pop's critical path
+    int spare;                       // a chunk popped ahead of need (-1: none); k_collect only (GameCtl::spare between launches)
 };
 // n contiguous slots (n <= chunk_slots) for the tree, from its current chunk or a fresh one off the pool; -1 = the game's cap
 // (max_chunks) or the pool is exhausted.  Called by the whole wave; every lane gets the same answer.
@@ -111,8 +116,8 @@ __device__ __forceinline__ int tree_alloc(const EngineDev& d, TreeAlloc& al, int
     if (n > room) {
         int id = -1;
         if (lane_id() == 0) {
-            const int have = al.ctl ? al.ctl->n_chunks : al.n_chunks;
-            if (have < d.sc.max_chunks) id = pool_pop(d);
+            const int have = al.n_chunks;
+            if (have < d.sc.max_chunks) id = al.spare >= 0 ? al.spare : pool_pop(d, al.visible);
             if (id >= 0) {
                 al.ids[have] = id;
                 if (al.ctl) { al.ctl->n_chunks = have + 1; const int hw = (have + 1) * d.sc.chunk_slots; if (hw > al.ctl->hw_slot) al.ctl->hw_slot = hw; }
@@ -120,6 +125,7 @@ __device__ __forceinline__ int tree_alloc(const EngineDev& d, TreeAlloc& al, int
         }
         id = __builtin_amdgcn_readfirstlane(id);
         if (id < 0) return -1;
+        al.spare = -1;
         ++al.n_chunks;
         al.free_slot = id * d.sc.chunk_slots;
     }
@@ -183,10 +189,11 @@ __global__ __launch_bounds__(64) void k_release(EngineDev d, const uint8_t* mask
     const int g = blockIdx.x;
     if (mask && !mask[g]) return;
     GameCtl* c = &d.ctl[g];
-    const int n = c->n_chunks;
+    const int n = c->n_chunks, sp = c->spare;
     pool_push(d, chunk_list(d, g, c->cur), n);
+    if (sp >= 0) pool_push(d, &c->spare, 1);
     __syncthreads();
-    if (lane_id() == 0) { c->n_chunks = 0; c->free_slot = 0; }
+    if (lane_id() == 0) { c->n_chunks = 0; c->free_slot = 0; c->spare = -1; }
 }
 
 // states == nullptr: empty boards (reset_root, self_play.py:595-598).  Otherwise the root of every masked game is the given
@@ -206,11 +213,11 @@ __global__ __launch_bounds__(64) void k_reset(EngineDev d, const uint8_t* mask, 
     GameCtl c = d.ctl[g];                                             // cumulative statistics survive a reset
     if (c.error && lane_id() == 0) atomicSub(&d.counters[CNT_ERRORS], 1);   // CNT_ERRORS = games parked in error right now
     // (the old tree's chunks went back to the pool in k_release, or the ring was just rebuilt with every chunk in it)
-    c.cur = 0; c.free_slot = 0; c.n_chunks = 0; c.root = 0;
+    c.cur = 0; c.free_slot = 0; c.n_chunks = 0; c.root = 0; c.spare = -1;
     c.n_target = 0; c.active = 0; c.n_paths = 0; c.need_eval = 0; c.root_row = 0;
     c.finished = 0; c.error = 0; c.searching = 0; c.moves = 0;
     NodeRec* arena = d.arena;
-    TreeAlloc al; al.ids = chunk_list(d, g, 0); al.n_chunks = 0; al.free_slot = 0; al.ctl = nullptr;
+    TreeAlloc al; al.ids = chunk_list(d, g, 0); al.n_chunks = 0; al.free_slot = 0; al.ctl = nullptr; al.visible = d.pool->visible; al.spare = -1;
     BoardState<S> st;
     if (states) st = states[g]; else state_reset(st);
     const bool over = st.terminated != 0;
@@ -307,9 +314,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
     int nslot = 0;                                   // evaluation-batch entries this game has written in this wave
     BoardWave<S> bw; bw.init(&lds);
     WaveRng rng; rng.key = d.rng[g].key; rng.pos = d.rng[g].pos; rng.scratch = mt_scratch; rng.draws = 0;
-    // one register of allocator state (wave-uniform: scalar); the chunk count stays in GameCtl (the kernel runs at a 128-VGPR budget)
-    TreeAlloc al; al.ids = chunk_list(d, g, __builtin_amdgcn_readfirstlane(c->cur)); al.n_chunks = 0; al.ctl = c;
+    // allocator state: wave-uniform, scalar registers; everything a new chunk needs is read HERE, with the kernel's other start-up
+    // loads, so that the new-chunk path is one returning atomic + one ring read (the kernel's time is its slowest game's)
+    TreeAlloc al; al.ids = chunk_list(d, g, __builtin_amdgcn_readfirstlane(c->cur)); al.n_chunks = __builtin_amdgcn_readfirstlane(c->n_chunks); al.ctl = c;
     al.free_slot = __builtin_amdgcn_readfirstlane(c->free_slot);
+    { const unsigned long long v = d.pool->visible;
+      al.visible = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v); }
+    // a wave may need a new chunk when fewer than R largest blocks fit the current one: the pop goes out NOW and its two round trips
+    // (ticket, ring entry) fly behind the first selection; a chunk that ends up unused waits in GameCtl::spare for the next wave
+    {
+        int sp = c->spare;
+        const int room0 = (-al.free_slot) & (sc.chunk_slots - 1);
+        if (TG_POOL_PREFETCH && sp < 0 && room0 < sc.R * (HS + G::A) && al.n_chunks < sc.max_chunks && lane == 0) sp = pool_pop(d, al.visible);
+        al.spare = __builtin_amdgcn_readfirstlane(sp);
+    }
     int* paths = d.path_nodes + (size_t)g * sc.R * sc.maxd;
     int npaths = 0, err = 0;
     int leafs[8], rows[8];
@@ -435,7 +453,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
     TG_ST_FLUSH();
     if (lane == 0) {
         d.game_nslot[g] = nslot;
-        c->n_paths = npaths; c->free_slot = al.free_slot; c->error |= err;
+        c->n_paths = npaths; c->free_slot = al.free_slot; c->spare = al.spare; c->error |= err;
         c->sims += sims; c->depth_sum += depth_sum; c->evals += evals; c->tie_draws += rng.draws; c->child_sum += child_sum;
         d.rng[g].pos = rng.pos;
         if (err) { atomicAdd(&d.counters[CNT_ERRORS], 1); c->searching = 0; c->active = 0; }
@@ -534,7 +552,7 @@ __global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions
     constexpr int HS = TreeGeo<S>::HS, NPASS = TreeGeo<S>::NPASS;
     __shared__ WaveLds<S> lds;
     __shared__ uint32_t bits_s[(13 * G::P + 31) / 32];
-    __shared__ int fill_s[kMaxChunks], cstart_s[kMaxChunks];   // chunk k of the new tree: first slot, and where its copied blocks end
+    __shared__ int fill_s[ChunkCap<S>::N], cstart_s[ChunkCap<S>::N];   // chunk k of the new tree: first slot, and where its copied blocks end
     const int g = blockIdx.x, lane = lane_id();
     GameCtl* c = &d.ctl[g];
     if (lane == 0) d.game_nslot[g] = 0;
@@ -572,7 +590,7 @@ __global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions
     const bool done = state_step(bw, st, a, d.rules, /*check=*/false, &ok);      // self_play.py:859
     NodeRec child = old[rblk + HS + idx];
     // the new tree grows in fresh chunks, recorded in the game's OTHER chunk-id list
-    TreeAlloc na; na.ids = chunk_list(d, g, c->cur ^ 1); na.n_chunks = 0; na.free_slot = 0; na.ctl = nullptr;
+    TreeAlloc na; na.ids = chunk_list(d, g, c->cur ^ 1); na.n_chunks = 0; na.free_slot = 0; na.ctl = nullptr; na.visible = d.pool->visible; na.spare = -1;
     const int nroot = tree_alloc(d, na, 1);
     if (nroot < 0) {                                                   // not one chunk left in the pool: the game is parked with its tree intact
         if (lane == 0) { c->error |= 1; c->searching = 0; c->active = 0; done_out[g] = 2; moves_out[g] = c->moves; atomicAdd(&d.counters[CNT_ERRORS], 1); }
@@ -874,13 +892,14 @@ int tg_engine_create(tg_ctx* ctx) {
     // leaves unused when it does not fit the current chunk is a few per cent; a game owns at least one chunk
     sc.chunk_slots = ctx->S == 9 ? 1024 : 4096;
     sc.max_chunks = (int)((slots + sc.chunk_slots - 1) / sc.chunk_slots) + 1;
-    if (sc.max_chunks > kMaxChunks) TG_FAIL(ctx, TG_ERR_ARG, "arena_slots too large for the chunk table (at most 2047 chunks per game)");
+    if (sc.max_chunks > (ctx->S == 9 ? ChunkCap<9>::N : ChunkCap<19>::N))
+        TG_FAIL(ctx, TG_ERR_ARG, "arena_slots too large for the chunk table (at most 511 chunks of 1024 slots per game at 9x9, 2047 of 4096 at 19x19)");
     // pool size: cfg.pool_slots slots per game ON AVERAGE (0: default_pool_slots below), at least two chunks per game and one
     // largest tree
     long long per_game = cfg.pool_slots > 0 ? cfg.pool_slots : tg_default_pool_slots(ctx->S, cfg.num_simulation);
     long long pool_chunks = ((long long)G * per_game + sc.chunk_slots - 1) / sc.chunk_slots;
     if (pool_chunks < 2LL * G + sc.max_chunks) pool_chunks = 2LL * G + sc.max_chunks;
-    if (pool_chunks * sc.chunk_slots > 0x7fffffffLL)
+    if (pool_chunks * sc.chunk_slots > 0x7ff00000LL)               // slot indices are int32 (and selection reads up to 64 slots past a block start)
         TG_FAIL(ctx, TG_ERR_ARG, "tree pool larger than 2^31 slots (64 GiB): lower pool_slots or n_games");
     sc.pool_chunks = (int)pool_chunks; sc.pool_slots = (int)(pool_chunks * sc.chunk_slots);
     e->dev.rules = ctx->rules;

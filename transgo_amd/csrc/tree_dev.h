@@ -59,6 +59,7 @@ struct GameCtl {
     int32_t free_slot;    // next unused slot (global index) in the chunk the live tree is growing in (on a chunk boundary = no room)
     int32_t n_chunks;     // chunks the live tree owns
     int32_t root;         // global slot of the root record
+    int32_t spare;        // a chunk taken off the pool ahead of need by k_collect and not used yet (-1: none); it stays with the game
     int32_t n_target;     // root visit target of the current move (self_play.py:662-663)
     int32_t active;       // still below target in this move
     int32_t n_paths;      // paths collected by the wave in flight

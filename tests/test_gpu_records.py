@@ -101,6 +101,56 @@ def test_harvest_feeds_the_device_replay_store_without_the_host():
     dev.close()
 
 
+def test_allgather_transport_on_device_buffers_with_a_simulated_peer(monkeypatch):
+    """The default finished-game transport over RCCL has never had a second rank on this project's one-GPU boxes.  Everything of it
+    that is not the collective itself -- padding the device harvest buffer, cutting the gathered buffers back to exact lengths,
+    handing a PEER's games to the device replay store as a view of the gathered buffer (no copy queued on torch's stream behind
+    which tg_replay_append_dev, on the library's own stream, would have to wait) -- runs here on the GPU with `all_gather` replaced
+    by a local stand-in that delivers a second rank's (different, longer) buffer."""
+    import torch
+    import torch.distributed as dist
+    from transgo_amd import distributed, records
+    from transgo_amd.configure import Config
+    from transgo_amd.replay_buffer import DeviceReplayMemory, ReplayMemory_Random
+    from transgo_amd.self_play import BatchedSelfPlay
+    cfg = Config(num_simulation=16, max_step=6, buffer_size=8 * 4096)
+    dev = torch.device("cuda", 0)
+
+    def finished(n_games, seed0):
+        sp = BatchedSelfPlay(cfg, n_games, evaluator=evaluators.flat, seed_fn=lambda g, k: seed0 + g + 100 * k)
+        for _ in range(6):
+            h = sp.advance(device=True)
+        assert h is not None and h.on_device and h.n_games == n_games
+        return h
+    mine, peer = finished(5, 10), finished(3, 500)                    # rank 0 finished 5 games, "rank 1" 3: its buffer arrives padded
+    sizes = [(mine.n_games, mine.n_positions), (peer.n_games, peer.n_positions)]
+
+    def fake_all_gather(bucket, pad):
+        assert pad.is_cuda and len(bucket) == 2 and all(b.is_cuda and b.numel() == pad.numel() for b in bucket)
+        bucket[0].copy_(pad)
+        bucket[1].zero_(); bucket[1][:peer.nbytes] = peer.buf
+    monkeypatch.setattr(dist, "all_gather", fake_all_gather)
+    monkeypatch.delenv("TRANSGO_GATHER", raising=False)
+    out = distributed._gather_payloads(mine, 9, 10, 0, sizes, 2, 0, True, dev)
+    assert len(out) == 2 and out[0] is mine and out[1].on_device and out[1].nbytes == peer.nbytes < out[1].buf.untyped_storage().nbytes()
+    assert torch.equal(out[1].buf, peer.buf)
+    store, host = DeviceReplayMemory(cfg, capacity_positions=1024), ReplayMemory_Random(cfg)
+    for hb in out:
+        store.append_harvest(hb)
+        for t in hb.targets():
+            host.append(*t)
+    n = host.info()["index"]
+    assert store.info()["entries"] == n == (mine.n_positions + peer.n_positions) * 8
+    idx = np.arange(n)
+    s, p, z, o = map(np.stack, zip(*host.data[idx]))
+    s, p, z, o = (torch.FloatTensor(a).numpy() for a in (s, p, z, o))
+    ds, dp, dz, do = store.sample_entries(idx)
+    assert np.array_equal(ds, s) and np.array_equal(dp, p) and np.array_equal(dz, z) and np.array_equal(do, o)
+    # a rank that is not the owner contributes and receives nothing
+    assert distributed._gather_payloads(peer, 9, 10, 0, sizes, 2, 1, True, dev) == []
+    store.close()
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 

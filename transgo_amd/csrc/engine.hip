@@ -39,7 +39,9 @@ __device__ unsigned long long g_stamp[16], g_stamp2[8];
                                                      // read-modify-write (0.207 vs 0.203 ms per wave, profiles/r4_ab_tree_counters.txt): not the default
 #endif
 #ifndef TG_POOL_PREFETCH
-#define TG_POOL_PREFETCH 1                            // k_collect pops the chunk a wave may need at its start (0: on demand; A/B builds)
+#define TG_POOL_PREFETCH 0                            // 1: k_collect pops the chunk a wave may need at its start -- measured 2 % SLOWER on the tree stage
+                                                     // (0.2049 vs 0.2006 ms per wave, profiles/r4_ab_tree_prefetch.txt: a third of the games draw a
+                                                     // ticket every wave instead of a tenth): not the default
 #endif
 constexpr int kMaxPath = 512;                        // longest selection path kept in LDS (>= SearchCfg::maxd, checked at create)
 // most chunks one game's tree may own (>= SearchCfg::max_chunks, checked at create).  k_play keeps two ints per chunk of the new tree
@@ -71,15 +73,19 @@ __device__ __forceinline__ int pool_pop(const EngineDev& d, unsigned long long v
     if (h >= vis) { atomicAdd(&pc->exhausted, 1ull); return -1; }
     return d.ring[h % (unsigned long long)d.sc.pool_chunks];
 }
-// n chunk ids back onto the ring (whole wave; poppable once k_pool_publish has run behind this kernel)
-__device__ __forceinline__ void pool_push(const EngineDev& d, const int32_t* ids, int n) {
-    if (n <= 0) return;
+// n (+ n2) chunk ids back onto the ring with ONE draw on `tail` (whole wave; poppable once k_pool_publish has run behind this
+// kernel).  Returning atomics of 4096 workgroups on one address cost ~12 ns each: every draw saved is 50 us of a k_play launch.
+__device__ __forceinline__ void pool_push(const EngineDev& d, const int32_t* ids, int n, const int32_t* ids2 = nullptr, int n2 = 0) {
+    if (n < 0) n = 0;
+    if (n2 < 0) n2 = 0;
+    if (n + n2 <= 0) return;
     const int lane = lane_id();
     unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(&d.pool->tail, (unsigned long long)n);
+    if (lane == 0) base = atomicAdd(&d.pool->tail, (unsigned long long)(n + n2));
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32));
     base = ((unsigned long long)hi << 32) | lo;
     for (int i = lane; i < n; i += 64) d.ring[(base + i) % (unsigned long long)d.sc.pool_chunks] = ids[i];
+    for (int i = lane; i < n2; i += 64) d.ring[(base + n + i) % (unsigned long long)d.sc.pool_chunks] = ids2[i];
 }
 // every chunk free (creation, and a reset of all games); the statistics survive a reset
 __global__ void k_pool_init(EngineDev d, int first) {
@@ -108,6 +114,7 @@ struct TreeAlloc {
     int32_t* ids; int n_chunks, free_slot; GameCtl* ctl;
     unsigned long long visible;      // PoolCtl::visible, read once at the top of the kernel (constant during a launch): off the pop's critical path
     int spare;                       // a chunk popped ahead of need (-1: none); k_collect only (GameCtl::spare between launches)
+    const int* rsv; int rsv_n, rsv_i; // chunk ids reserved with ONE ticket draw (k_play: LDS table), handed out before single pops
 };
 // n contiguous slots (n <= chunk_slots) for the tree, from its current chunk or a fresh one off the pool; -1 = the game's cap
 // (max_chunks) or the pool is exhausted.  Called by the whole wave; every lane gets the same answer.
@@ -117,7 +124,7 @@ __device__ __forceinline__ int tree_alloc(const EngineDev& d, TreeAlloc& al, int
         int id = -1;
         if (lane_id() == 0) {
             const int have = al.n_chunks;
-            if (have < d.sc.max_chunks) id = al.spare >= 0 ? al.spare : pool_pop(d, al.visible);
+            if (have < d.sc.max_chunks) id = al.spare >= 0 ? al.spare : al.rsv_i < al.rsv_n ? al.rsv[al.rsv_i] : pool_pop(d, al.visible);
             if (id >= 0) {
                 al.ids[have] = id;
                 if (al.ctl) { al.ctl->n_chunks = have + 1; const int hw = (have + 1) * d.sc.chunk_slots; if (hw > al.ctl->hw_slot) al.ctl->hw_slot = hw; }
@@ -125,7 +132,7 @@ __device__ __forceinline__ int tree_alloc(const EngineDev& d, TreeAlloc& al, int
         }
         id = __builtin_amdgcn_readfirstlane(id);
         if (id < 0) return -1;
-        al.spare = -1;
+        if (al.spare >= 0) al.spare = -1; else if (al.rsv_i < al.rsv_n) ++al.rsv_i;
         ++al.n_chunks;
         al.free_slot = id * d.sc.chunk_slots;
     }
@@ -190,8 +197,7 @@ __global__ __launch_bounds__(64) void k_release(EngineDev d, const uint8_t* mask
     if (mask && !mask[g]) return;
     GameCtl* c = &d.ctl[g];
     const int n = c->n_chunks, sp = c->spare;
-    pool_push(d, chunk_list(d, g, c->cur), n);
-    if (sp >= 0) pool_push(d, &c->spare, 1);
+    pool_push(d, chunk_list(d, g, c->cur), n, &c->spare, sp >= 0 ? 1 : 0);
     __syncthreads();
     if (lane_id() == 0) { c->n_chunks = 0; c->free_slot = 0; c->spare = -1; }
 }
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(64) void k_reset(EngineDev d, const uint8_t* mask, 
     c.n_target = 0; c.active = 0; c.n_paths = 0; c.need_eval = 0; c.root_row = 0;
     c.finished = 0; c.error = 0; c.searching = 0; c.moves = 0;
     NodeRec* arena = d.arena;
-    TreeAlloc al; al.ids = chunk_list(d, g, 0); al.n_chunks = 0; al.free_slot = 0; al.ctl = nullptr; al.visible = d.pool->visible; al.spare = -1;
+    TreeAlloc al; al.ids = chunk_list(d, g, 0); al.n_chunks = 0; al.free_slot = 0; al.ctl = nullptr; al.visible = d.pool->visible; al.spare = -1; al.rsv = nullptr; al.rsv_n = al.rsv_i = 0;
     BoardState<S> st;
     if (states) st = states[g]; else state_reset(st);
     const bool over = st.terminated != 0;
@@ -320,6 +326,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 9 ? 4 :
     al.free_slot = __builtin_amdgcn_readfirstlane(c->free_slot);
     { const unsigned long long v = d.pool->visible;
       al.visible = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v); }
+    al.rsv = nullptr; al.rsv_n = al.rsv_i = 0;
     // a wave may need a new chunk when fewer than R largest blocks fit the current one: the pop goes out NOW and its two round trips
     // (ticket, ring entry) fly behind the first selection; a chunk that ends up unused waits in GameCtl::spare for the next wave
     {
@@ -553,6 +560,7 @@ __global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions
     __shared__ WaveLds<S> lds;
     __shared__ uint32_t bits_s[(13 * G::P + 31) / 32];
     __shared__ int fill_s[ChunkCap<S>::N], cstart_s[ChunkCap<S>::N];   // chunk k of the new tree: first slot, and where its copied blocks end
+    __shared__ int rsv_s[64];                          // chunk ids reserved for the new tree with one ticket draw
     const int g = blockIdx.x, lane = lane_id();
     GameCtl* c = &d.ctl[g];
     if (lane == 0) d.game_nslot[g] = 0;
@@ -591,8 +599,26 @@ __global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions
     NodeRec child = old[rblk + HS + idx];
     // the new tree grows in fresh chunks, recorded in the game's OTHER chunk-id list
     TreeAlloc na; na.ids = chunk_list(d, g, c->cur ^ 1); na.n_chunks = 0; na.free_slot = 0; na.ctl = nullptr; na.visible = d.pool->visible; na.spare = -1;
+    // ONE ticket draw for the chunks the new tree is expected to need (the kept sub-tree has at most one block per visit of the
+    // chosen child; ~48 slots each): 4096 games drawing their chunks one by one serialise on the ring's head (the launch took 0.22 ms
+    // instead of 0.09 with 64-simulation searches).  What is not used goes back with the old tree's chunks.
+    {
+        int want = 1;
+        if (child.flags & F_OPEN) { want += (int)(((long long)child.n * 48 + sc.chunk_slots - 1) / sc.chunk_slots); }
+        want = want > 64 ? 64 : want > sc.max_chunks ? sc.max_chunks : want;
+        unsigned long long h0 = 0;
+        if (lane == 0) h0 = atomicAdd(&d.pool->head, (unsigned long long)want);
+        h0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(h0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)h0);
+        const long long avail = (long long)(na.visible - h0);          // tickets at or beyond `visible` are failures (k_pool_publish takes them back)
+        const int valid = avail <= 0 ? 0 : avail >= want ? want : (int)avail;
+        if (valid < want && lane == 0) atomicAdd(&d.pool->exhausted, 1ull);
+        if (lane < valid) rsv_s[lane] = d.ring[(h0 + lane) % (unsigned long long)sc.pool_chunks];
+        __syncthreads();
+        na.rsv = rsv_s; na.rsv_n = valid; na.rsv_i = 0;
+    }
     const int nroot = tree_alloc(d, na, 1);
     if (nroot < 0) {                                                   // not one chunk left in the pool: the game is parked with its tree intact
+        pool_push(d, na.rsv + na.rsv_i, na.rsv_n - na.rsv_i);
         if (lane == 0) { c->error |= 1; c->searching = 0; c->active = 0; done_out[g] = 2; moves_out[g] = c->moves; atomicAdd(&d.counters[CNT_ERRORS], 1); }
         return;
     }
@@ -661,8 +687,8 @@ __global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions
         // so even when the game just ended; that evaluation has no observable effect and is skipped here.
         if (!done) { bw.load_colors(st.bb[0], st.bb[1]); bw.analyze(); }
         const int blk = make_block(bw, st, nw, d, na, !done);
-        if (blk < 0) {                                                 // pool exhausted: park the game (old tree intact), give the new chunk back
-            pool_push(d, na.ids, na.n_chunks);
+        if (blk < 0) {                                                 // pool exhausted: park the game (old tree intact), give the new chunks back
+            pool_push(d, na.ids, na.n_chunks, na.rsv + na.rsv_i, na.rsv_n - na.rsv_i);
             if (lane == 0) { c->error |= 1; c->searching = 0; c->active = 0; done_out[g] = 2; moves_out[g] = c->moves; atomicAdd(&d.counters[CNT_ERRORS], 1); }
             return;
         }
@@ -674,8 +700,8 @@ __global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions
         }
     }
     __syncthreads();
-    // the old tree's chunks go back to the pool (poppable after k_pool_publish)
-    pool_push(d, chunk_list(d, g, c->cur), c->n_chunks);
+    // the old tree's chunks, and what was reserved and not needed, go back to the pool (poppable after k_pool_publish)
+    pool_push(d, chunk_list(d, g, c->cur), c->n_chunks, na.rsv + na.rsv_i, na.rsv_n - na.rsv_i);
     if (lane == 0) {
         c->cur ^= 1; c->free_slot = na.free_slot; c->n_chunks = na.n_chunks; c->root = nroot;
         if (na.n_chunks * sc.chunk_slots > c->hw_slot) c->hw_slot = na.n_chunks * sc.chunk_slots;

@@ -117,7 +117,10 @@ def _gather_payloads(h, S, C, dst, sizes, world, rank, nccl, dev):
         for r, (g, n) in enumerate(sizes):
             if g:
                 nb = records.layout(S, C, g, n)[1]
-                out.append(h if r == dst else records.Harvest(S, C, g, n, bucket[r][:nb].clone() if nccl else bucket[r][:nb].numpy().copy()))
+                # over RCCL a VIEW of the gathered buffer (it lives as long as the Harvest does): the synchronize above covers the
+                # collective, and nothing else is queued on torch's stream that the library -- which reads the buffer next on ITS
+                # OWN stream (tg_replay_append_dev) -- would have to wait for (a clone made here would be exactly that)
+                out.append(h if r == dst else records.Harvest(S, C, g, n, bucket[r][:nb] if nccl else bucket[r][:nb].numpy().copy()))
         return out
     ops, recv = [], {}
     if rank == dst:

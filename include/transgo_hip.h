@@ -32,7 +32,7 @@ typedef enum tg_status {
     TG_ERR_ARG = -1,        /* bad argument / unsupported configuration */
     TG_ERR_HIP = -2,        /* HIP runtime error (message has the HIP error string) */
     TG_ERR_NO_DEVICE = -3,  /* no usable GPU: the library has no CPU fallback */
-    TG_ERR_ARENA = -4,      /* a game's tree arena overflowed (results of that game are invalid) */
+    TG_ERR_ARENA = -4,      /* a game's tree hit its cap (cfg.arena_slots) or found the shared pool empty (results of that game are invalid) */
     TG_ERR_STATE = -5       /* call sequence violated (e.g. absorb without collect) */
 } tg_status;
 
@@ -165,10 +165,11 @@ int tg_sp_rng_state(tg_ctx* ctx, int game, tg_mt19937* out);
 int tg_sp_rng_get(tg_ctx* ctx, tg_mt19937* out /*[G]*/);
 int tg_sp_rng_set(tg_ctx* ctx, const tg_mt19937* in /*[G]*/, const uint8_t* mask /*[G] or NULL*/);
 /* update_with_action (self_play.py:857-872) for every unfinished game; done[g] = 1 game over, 2 the game is parked in
- * error (tree arena overflow; see tg_sp_game_errors), 0 otherwise.  With cfg.record_games the move's record entry is
+ * error (tree cap reached / pool empty; see tg_sp_game_errors), 0 otherwise.  With cfg.record_games the move's record entry is
  * written first (self_play.py:917-926).  Leaves a root batch pending for the games whose new root was not yet expanded. */
 int tg_sp_play(tg_ctx* ctx, const int32_t* actions /*[G]*/, uint8_t* done /*[G]*/);
-/* A game whose tree outgrows its arena (cfg.arena_slots) is parked: it takes no further part in searches, tg_sp_play reports
+/* A game whose tree outgrows its cap (cfg.arena_slots), or that finds the shared pool (cfg.pool_slots) empty, is parked: it takes no
+ * further part in searches (its chunks stay its own until its slot is reset), tg_sp_play reports
  * 2 for it, every other game is unaffected, and tg_sp_reset with its mask bit starts a new game in the slot.  n_errors = games
  * parked right now (as of the last collect/play; no device round trip when err is NULL); err[g] = 0 or a bit set (1 arena,
  * 2 path depth, 4 action not among the root's children). */
@@ -202,7 +203,8 @@ int tg_sp_harvest(tg_ctx* ctx, uint32_t* obs_bits, int32_t* counts, float* z, in
 /* getScoreAndTerritory / getWinner of the current root position (self_play.py:932-937). */
 int tg_sp_final(tg_ctx* ctx, float* score /*[G]*/, float* terr /*[G][S*S]*/, int32_t* winner /*[G]*/);
 /* Aggregate counters: completed simulations, evaluated leaves, summed selection depth, RNG words drawn by tie
- * breaks, games in error, high-water mark of arena slots. */
+ * breaks, games in error, and max_slots = the most slots any single game's tree has held (whole chunks; the pool's own fill is
+ * tg_sp_pool_stats). */
 int tg_sp_stats(tg_ctx* ctx, uint64_t* sims, uint64_t* evals, uint64_t* depth_sum, uint64_t* tie_draws, int32_t* errors,
                 int32_t* max_slots);
 

@@ -603,7 +603,8 @@ def main(argv=None):
                     else f"reference MainNetwork (RARRRARRRRAR+P, {a.filters} filters)")
         gph_step = round(world * a.games * 3600.0 / (dt / a.steps * mean_len), 1) if mean_len else None
         line = {
-            "metric": "MCTS simulations/sec", "value": round(value, 1), "unit": "sims/s", "n_gpus": world,
+            "metric": "REHEARSAL with a stand-in engine (not MCTS simulations/sec)" if standin else "MCTS simulations/sec",
+            "value": round(value, 1), "unit": "stand-in steps/s" if standin else "sims/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
             "data": "stand-in engine (CPU rehearsal of the N-rank control flow: NOT a measurement)" if standin else "synthetic",

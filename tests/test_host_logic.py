@@ -547,7 +547,7 @@ def test_bench_launcher_world8_rehearsal_with_the_stand_in_engine():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     line = json.loads(lines[0])
-    assert "NOT a measurement" in line["data"] and line["n_gpus"] == 8 and line["scaling"] == "weak"
+    assert "NOT a measurement" in line["data"] and "REHEARSAL" in line["metric"] and line["n_gpus"] == 8 and line["scaling"] == "weak"
     rk = line["ranks"]
     assert rk["world"] == 8 and rk["backend"] == "gloo" and rk["launcher"] == "bench.py" and rk["seeds_disjoint"] is True
     assert len({d["pid"] for d in rk["devices"]}) == 8 and sorted(d["rank"] for d in rk["devices"]) == list(range(8))

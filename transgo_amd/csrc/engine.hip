@@ -605,7 +605,8 @@ __global__ __launch_bounds__(64) void k_play(EngineDev d, const int32_t* actions
     {
         int want = 1;
         if (child.flags & F_OPEN) { want += (int)(((long long)child.n * 48 + sc.chunk_slots - 1) / sc.chunk_slots); }
-        want = want > 64 ? 64 : want > sc.max_chunks ? sc.max_chunks : want;
+        want = want > sc.max_chunks ? sc.max_chunks : want;
+        want = want > 64 ? 64 : want;
         unsigned long long h0 = 0;
         if (lane == 0) h0 = atomicAdd(&d.pool->head, (unsigned long long)want);
         h0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(h0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)h0);

@@ -45,6 +45,21 @@ PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f3
 PEAK_F16_MATRIX_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense F16/BF16 MFMA (v_mfma_f32_16x16x32_f16), ~2.5 PFLOP/s
 
 
+def net_source_hash():
+    """Identity of the network kernels' source for the PMC traffic figure: sha256 of transgo_amd/csrc/net.hip with comments and
+    blank space removed (a comment edit does not make a collected figure stale, a code edit does).  None without the source."""
+    import hashlib
+    import re
+    src = os.path.join(ROOT, "transgo_amd", "csrc", "net.hip")
+    if not os.path.exists(src):
+        return None
+    txt = open(src, encoding="utf-8", errors="replace").read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", "", txt)
+    txt = "".join(txt.split())
+    return hashlib.sha256(txt.encode()).hexdigest()[:16]
+
+
 def flops_per_leaf(S, C, F, N):
     P = S * S
     return 2 * 9 * P * (C * F + 2 * N * F * F) + 2 * 9 * P * F * 6 + 2 * 4 * P * (P + 1) + 2 * 2 * P * 64 + 2 * 64 * (1 + P)
@@ -577,12 +592,10 @@ def main(argv=None):
         tname = {"f32": "pmc_traffic.json", "f32x3": "pmc_f32x3.json"}.get(a.dtype)
         tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if tname and f.endswith("_" + tname)) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
         if tfiles and (S, a.filters, a.games, a.network) == (9, 128, 4096, "tower"):
-            import hashlib
             tfile = os.path.join(ROOT, "profiles", tfiles[-1])                # the latest round's
             with open(tfile) as f:
                 pj = json.load(f)
-            src = os.path.join(ROOT, "transgo_amd", "csrc", "net.hip")
-            now = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16] if os.path.exists(src) else None
+            now = net_source_hash()
             if pj.get("net_hip_sha16") and pj["net_hip_sha16"] == now:
                 traffic = pj.get("hbm_bytes_per_launch_mean")
                 tnote = f"HBM bytes per full-batch launch, FETCH_SIZE x2 + WRITE_SIZE (profiles/{tfiles[-1]}, collected on this build of net.hip)"

@@ -56,9 +56,10 @@ tc, ta = out["kernels"]["k_collect<9>"], out["kernels"]["k_absorb<9>"]
 out["tree_stage"] = {"hbm_bytes_per_wave": tc["hbm_bytes_per_launch"] + ta["hbm_bytes_per_launch"],
                      "note": "k_collect + k_absorb per search wave (4096 games x up to 4 read-outs, ~16 k simulations); bench.py prices the same wave at "
                              "bytes_per_sim x sims (roofline_tree); the 32-B-record reads are outside the FETCH_SIZE calibration, so treat the ratio as indicative"}
-import hashlib, os
-_src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "transgo_amd", "csrc", "net.hip")
-out["net_hip_sha16"] = hashlib.sha256(open(_src, "rb").read()).hexdigest()[:16]      # bench.py reports `traffic` only for this build
+import os, sys as _sys
+_sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import net_source_hash
+out["net_hip_sha16"] = net_source_hash()      # bench.py reports `traffic` only while the network kernels' code is this (comments apart)
 json.dump(out, open(OUT, "w"), indent=1)
 for k, v in out["kernels"].items():
     if "conv3x3_sg" in k:

@@ -44,8 +44,9 @@ ks = list(out["kernels"].values())
 out["hbm_bytes_per_launch_mean"] = sum(v["hbm_bytes_per_launch"] for v in ks) / max(1, len(ks))
 out["bench_line_unprofiled"] = {"value_sims_per_s": line["value"], "conv_tflops_effective": line["roofline"]["achieved"], "frac_of_fp16_peak_over_3": line["roofline"]["frac"],
                                 "avg_launch_ms": line["roofline"]["avg_launch_ms"], "net_tflops_end_to_end": line["extra"]["net_tflops_end_to_end"]}
-import hashlib, os
-_src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "transgo_amd", "csrc", "net.hip")
-out["net_hip_sha16"] = hashlib.sha256(open(_src, "rb").read()).hexdigest()[:16]      # bench.py reports `traffic` only for this build
+import os, sys as _sys
+_sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import net_source_hash
+out["net_hip_sha16"] = net_source_hash()      # bench.py reports `traffic` only while the network kernels' code is this (comments apart)
 json.dump(out, open(OUT, "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])

@@ -45,6 +45,7 @@ struct Net {
     int prec = 0;                                  // cfg.net_precision: 0 = f32, 1 = fp16 storage + f32 accumulate (k_conv3x3_h2), 2 = 1 + fp16 residual stream,
                                                    // 3 = split precision ("f32x3"): every operand as fp16 hi + lo, three of the four products on the fp16 MFMA, f32 accumulate
     const float* head_g = nullptr; const float* head_ag = nullptr;   // [64][F] head conv weights for k_head_gemm (tap*6 + cout rows)
+    const _Float16* head_x2 = nullptr; const float* head_x2sc = nullptr;   // prec 3, F = 128: the value/policy head conv's split weights (k_head_gemm_x2) + 2^-s
     float* wsc = nullptr;                          // prec 3: [2*NB + 1] power-of-two factor 2^-s each conv's weights were scaled by before splitting (stem last)
     _Float16* stem_h = nullptr; _Float16* head_h = nullptr; _Float16* x0h = nullptr;   // fp16 path: stem [2*9][F][32] (16 planes padded to 64), head [F/32*9][16][32], input [rows][P][64]
     _Float16* wh = nullptr; _Float16* act16 = nullptr; _Float16* h16 = nullptr;   // fp16 path: weights [2*NB][F/32*9][F][32], activations [rows][P][F]
@@ -67,7 +68,8 @@ struct Net {
     // every kernel that may still read it.
     struct WeightSet { float* blob = nullptr; float* wstage = nullptr; _Float16* wh = nullptr; _Float16* stem_h = nullptr; _Float16* head_h = nullptr;
                        float* wsc = nullptr; float* head_g = nullptr; float* head_ag = nullptr;
-                       _Float16* att_h = nullptr; float* att_sc = nullptr; };                          // k_attention_x3: per attention layer, split weight image + scale   // head_g / head_ag: k_head_gemm copies of head / head_a
+                       _Float16* att_h = nullptr; float* att_sc = nullptr;
+                       _Float16* head_x2 = nullptr; float* head_x2sc = nullptr; };                          // k_attention_x3: per attention layer, split weight image + scale   // head_g / head_ag: k_head_gemm copies of head / head_a
     WeightSet sets[2]; int active = 0; bool pending = false;
     hipStream_t side = nullptr; hipEvent_t loaded = nullptr, swapped = nullptr; float* pinned = nullptr;
     // profiling of the dominant kernel (3x3 conv F->F) with HIP events on the launch stream
@@ -1238,6 +1240,112 @@ __global__ __launch_bounds__(256) void k_restage_head(const float* __restrict__ 
     }
 }
 
+// The same head conv for the split-precision chain (net_precision 3, F = 128): the GEMM runs on v_mfma_f32_16x16x32_f16 with the
+// activation rows taken from the split chunk-major conv input the last residual block wrote (relu(bn_end(x)) as fp16 hi | lo:
+// a lane's A fragment of a 16-channel group is ONE 16-B load, chunk plane g*4 + kq) and the weights as [w_hi | w_hi] and
+// [w_lo | w_lo] fragments in registers (dst of k_restage_head_split, scaled by a power of two): two K = 32 steps per (group,
+// N-tile) give all four partial products of (w_hi + w_lo)(a_hi + a_lo) -- a quarter of the f32 kernel's MFMA time, so the kernel
+// is bound by the 512 B per row it reads.  A wave holds the B fragments of two N-tiles (128 registers) for the whole kernel;
+// D through LDS and col2im as in k_head_gemm, the power-of-two scale undone there (exact).
+template <int S, int F>
+__global__ __launch_bounds__(256, 2) void k_head_gemm_x2(const _Float16* __restrict__ in, float* __restrict__ out, const _Float16* __restrict__ W2,
+                                                         const float* __restrict__ wsc_p, const float* __restrict__ bias, int M, int ntiles) {
+    constexpr int P = S * S, HALO = S + 1, NTW = S == 9 ? 3 : 4, NROW = 64 * NTW, TM = NROW - 2 * HALO, LDW = 68, NG = F / 16;
+    constexpr int NTP = 2;                                                
+    __shared__ __attribute__((aligned(16))) float dl[NROW * LDW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, kq = lane >> 4;
+    const float wsc = wsc_p[0];
+    auto load_a = [&](f32x4* a, int row) {                              // group g: 8 halfs = chunk plane g*4 + kq of row `row`
+        const bool ok = row >= 0 && row < M;
+        const _Float16* src = in + ((size_t)kq * M + (ok ? row : 0)) * 8;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) a[g] = ok ? *reinterpret_cast<const f32x4*>(src + (size_t)g * 4 * M * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    f32x4 bh[NTP][NG], bl[NTP][NG];                                     // B fragments of column n = nt*16 + j: hi and lo halves
+    auto load_b = [&](int pass) {
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const _Float16* w = W2 + ((size_t)((pass * NTP + nt) * 16 + j) * NG + g) * 32;
+                bh[nt][g] = *reinterpret_cast<const f32x4*>(w + (kq & 1) * 8);
+                bl[nt][g] = *reinterpret_cast<const f32x4*>(w + 16 + (kq & 1) * 8);
+            }
+    };
+    // waves 0, 1 take N-tiles {0, 1}, waves 2, 3 take {2, 3}: a wave's B fragments are loaded ONCE per kernel; the two waves of a
+    // pair split the row tiles of a tile between them (every row tile is read by one wave of each pair)
+    const int nh = wave >> 1, wr = wave & 1;
+    load_b(nh);
+    constexpr int RTW = 2 * NTW;                                        // row tiles per wave
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * TM, r0 = m0 - HALO;
+        {
+            const int pass = nh;
+            f32x4 cur[NG];                                              // one buffer: the next row tile is requested right behind this one's
+            load_a(cur, r0 + (wr * RTW) * 16 + j);                      // MFMAs and lands while its D tile goes to LDS (128 registers are
+#pragma unroll 1                                                         // the weights': a second A buffer spills)
+            for (int i = 0; i < RTW; ++i) {
+                const int rt = wr * RTW + i, row = r0 + rt * 16 + j;
+                f32x4 acc[NTP];
+#pragma unroll
+                for (int nt = 0; nt < NTP; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int nt = 0; nt < NTP; ++nt) {
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, cur[g]), __builtin_bit_cast(h8, bh[nt][g]), acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, cur[g]), __builtin_bit_cast(h8, bl[nt][g]), acc[nt], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + 1 < RTW) load_a(cur, row + 16);
+                // D tile: row = A's M index = kq*4 + r, column = B's N index = j
+#pragma unroll
+                for (int nt = 0; nt < NTP; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dl[(rt * 16 + kq * 4 + r) * LDW + (pass * NTP + nt) * 16 + j] = acc[nt][r];
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < TM * 8; idx += 256) {
+            const int o = idx >> 3, co = idx & 7, m = m0 + o;
+            if (m >= M) continue;
+            float v = 0.f;
+            if (co < 6) {
+                const int p = m % P, x = p % S, y = p / S;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                    if (y + dy >= 0 && y + dy < S && x + dx >= 0 && x + dx < S) v += dl[(o + HALO + dy * S + dx) * LDW + tap * 6 + co];
+                }
+                v = v * wsc + bias[co];
+                v = v > 0.f ? v : 0.f;
+            }
+            out[(size_t)m * 16 + co] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// its weights: dst[n = tap*6 + co][group of 16 channels][w_hi 16 | w_lo 16] of w * 2^s (w is [9][16][F]; rows 54..63 zero; s puts the
+// largest weight in [2^14, 2^15) like k_restage_split); wsc_out = 2^-s
+__global__ __launch_bounds__(256) void k_restage_head_split(const float* __restrict__ w, _Float16* __restrict__ dst, float* __restrict__ wsc_out,
+                                                            const unsigned* __restrict__ maxbits, int F) {
+    const unsigned mb = maxbits[0];
+    int sh = mb ? 14 - ((int)((mb >> 23) & 0xffu) - 127) : 0;
+    sh = sh < -60 ? -60 : sh > 60 ? 60 : sh;
+    const float scale = ldexpf(1.f, sh);
+    if (blockIdx.x == 0 && threadIdx.x == 0) wsc_out[0] = ldexpf(1.f, -sh);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 64 * F; i += gridDim.x * 256) {
+        const int n = i / F, c = i % F, g = c >> 4, e = c & 15;
+        const float v = n < 54 ? w[((size_t)(n / 6) * 16 + n % 6) * F + c] * scale : 0.f;
+        const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+        _Float16* d = dst + ((size_t)n * (F / 16) + g) * 32;
+        d[e] = hi; d[16 + e] = lo;
+    }
+}
+
 // Self_Attention core (model.py:301-315) for one board per workgroup, after the fused q/k/v 1x1 projection:
 //   energy[i][j] = q_i . k_j ; attention = softmax_j(energy) ; out[:, j] = sum_i v[:, i] * attention[i][j]   (note: summed over
 //   the softmaxed ROW index i, exactly as torch.bmm(proj_value, attention) does)
@@ -1937,6 +2045,9 @@ __global__ __launch_bounds__(256) void k_heads(const float* __restrict__ hc, con
         hin[r][k] = r < nr ? (c < 2 ? hc : hca)[((size_t)(row0 + r) * P + p) * 16 + c] : 0.f;
     }
     __syncthreads();
+    // (spreading the rows of the workgroup over all 256 threads -- two / four row groups, each thread half / a quarter of the rows,
+    // the same fmaf chains -- was measured: 135 us per launch against 92; the loops are bound by their weight loads, whose number per
+    // thread stays the same and whose total doubles.  Splitting the input range instead would change the summation order.)
     if (tid < 64) {                                                   // fc_val_own + ReLU (model.py:99)
         float a[HR];
 #pragma unroll
@@ -2039,7 +2150,8 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
         if (n->prec == 3) {
             // Split-precision chain ("f32x3"): the f32 tower's arithmetic with every conv operand carried as fp16 hi + lo and all
             // three of the four partial products on the fp16 matrix cores (k_conv3x3_h2<..., X2>): stem and tower convs; the residual stream
-            // stays f32 row-major, the narrow head conv and the dense heads are the f32 kernels.  Opt-in: not the default path.
+            // stays f32 row-major, the dense heads are the f32 kernel, the narrow head conv runs split as well at 128 filters
+            // (k_head_gemm_x2).  Opt-in: not the default path.
             if ((long long)M * F * 4 >= (1ll << 31)) TG_FAIL(ctx, TG_ERR_ARG, "split-precision path: rows * P * F * 4 bytes must stay below 2 GiB per activation buffer");
             const int grid_h = (M + 255) / 256;
             constexpr int COS = F / 128;
@@ -2053,8 +2165,14 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
             // layer reads and writes the f32 residual stream with the f32 kernels (1x1 q/k/v projection + k_attention_mfma) and,
             // when a residual block follows, hands it relu(bn1_next(y)) already split (X2O).
             const size_t nl = n->layers.size();
+            // the head conv on the split fp16 MFMA too (k_head_gemm_x2, F = 128): the LAST residual block then writes relu(bn_end(.))
+            // split, as it would for a block behind it, and -- when nothing else reads the f32 stream (no attention in the policy
+            // head) -- leaves the stream itself unwritten (TG_HEAD_X2=0: the f32 head conv)
+            static const bool head_x2_on = !(getenv("TG_HEAD_X2") && atoi(getenv("TG_HEAD_X2")) == 0);
+            const bool x2_head = F == 128 && head_x2_on && n->head_x2 && nl && n->layers[nl - 1].kind == 0;
             auto next_bn = [&](size_t i, const float** sn, const float** tn) -> bool {   // layer i+1 is a residual block?
                 if (i + 1 < nl && n->layers[i + 1].kind == 0) { const BlockW& nb2 = n->blocks[n->layers[i + 1].ridx]; *sn = nb2.s1; *tn = nb2.t1; return true; }
+                if (i + 1 == nl && x2_head) { *sn = n->s_end; *tn = n->t_end; return true; }
                 *sn = nullptr; *tn = nullptr; return false;
             };
             constexpr int WQ = F / 4 + F / 4 + F;
@@ -2104,15 +2222,26 @@ int forward_t(tg_ctx* ctx, Net* n, const float* obs, int rows, float* policy, fl
                   hipLaunchKernelGGL((k_conv3x3_h2<S, 2 * F, F, 0, false, true>), dim3(nblk_h2), dim3(256), 0, st, (const _Float16*)n->act16,
                                      (float*)nullptr, n->h16, (const float*)nullptr, b.h1, b.c1.b, (const float*)nullptr, (const float*)nullptr, M, nblk_h2,
                                      wsc + 2 * L.ridx, n->range); }
+                float* const y32 = (i + 1 == nl && x2_head && !n->pol_att) ? (float*)nullptr : y;     // nothing reads the last block's f32 stream
                 { ProfScope ps(n, st, conv_flops);
                   hipLaunchKernelGGL((k_conv3x3_h2<S, 2 * F, F, 1, false, true>), dim3(nblk_h2), dim3(256), 0, st, (const _Float16*)n->h16,
-                                     y, act ? n->act16 : (_Float16*)nullptr, (const float*)x, b.h2, b.c2.b, sn, tn, M, nblk_h2, wsc + 2 * L.ridx + 1, n->range); }
+                                     y32, act ? n->act16 : (_Float16*)nullptr, (const float*)x, b.h2, b.c2.b, sn, tn, M, nblk_h2, wsc + 2 * L.ridx + 1, n->range); }
                 float* t = x; x = y; y = t;
             }
-            // the head conv is 16 couts wide (one MFMA tile): the f32 kernel reads the f32 residual stream and activates while staging
-            head_conv(x, n->hc, n->head_g, n->head, n->s_end, n->t_end);
+            if (x2_head) {
+                if constexpr (F == 128) {
+                    constexpr int TMH = 64 * (S == 9 ? 3 : 4) - 2 * (S + 1);
+                    const int nt = (M + TMH - 1) / TMH, g = nt < 512 ? nt : 512;
+                    hipLaunchKernelGGL((k_head_gemm_x2<S, F>), dim3(g), dim3(256), 0, st, (const _Float16*)n->act16, n->hc, n->head_x2, n->head_x2sc, n->head.b, M, nt);
+                }
+            } else {
+                // the head conv is 16 couts wide (one MFMA tile): the f32 kernel reads the f32 residual stream and activates while staging
+                head_conv(x, n->hc, n->head_g, n->head, n->s_end, n->t_end);
+            }
             const float* hca3 = n->hc;
-            if (n->pol_att) {                              // attention in the policy head (model.py:72,106-107), f32 kernels
+            if (n->pol_att) {                              // attention in the policy head (model.py:72,106-107), f32 head conv behind it
+                // (the policy head conv on the split MFMA as well was measured: what it saves the attention block's extra split write
+                // of its output costs -- 723.3 vs 723.2 k sims/s -- so it reads the f32 output)
                 attention_x2(n->patt, x, y, n->s_end, n->t_end, (_Float16*)nullptr, (const float*)nullptr, (const float*)nullptr);
                 head_conv(y, n->hca, n->head_ag, n->head_a, nullptr, nullptr);
                 hca3 = n->hca;
@@ -2354,6 +2483,7 @@ void bind_weights(Net* n, int k) {
     const int F = n->F; const size_t P = n->P, A = n->A, Wq = (size_t)F / 4 * 2 + F;
     const Net::WeightSet& w = n->sets[k];
     n->blob = w.blob; n->wstage = w.wstage; n->wh = w.wh; n->stem_h = w.stem_h; n->head_h = w.head_h; n->wsc = w.wsc; n->head_g = w.head_g; n->head_ag = w.head_ag;
+    n->head_x2 = w.head_x2; n->head_x2sc = w.head_x2sc;
     std::string trunk; bool pol = false;
     parse_arch(n->arch, &trunk, &pol);
     const float* p = w.blob;
@@ -2439,6 +2569,12 @@ int fill_weight_set(tg_ctx* ctx, Net* n, int k, const float* blob, hipStream_t s
         hipLaunchKernelGGL(k_absmax, dim3(64), dim3(256), 0, st, view.stem.w, (size_t)9 * F * 16, mx + ci);
         hipLaunchKernelGGL(k_restage_split, dim3(256), dim3(256), 0, st, view.stem.w, view.stem_h, n->sets[k].wsc + ci, (const unsigned*)(mx + ci),
                            F, 16, 2, 1);                                              // 16 planes = one group, padded to two (an even stage count)
+        if (n->sets[k].head_x2) {
+            unsigned* hmx = reinterpret_cast<unsigned*>(n->sets[k].head_x2sc) + 1;
+            TG_HIP(ctx, hipMemsetAsync(hmx, 0, sizeof(unsigned), st));
+            hipLaunchKernelGGL(k_absmax, dim3(16), dim3(256), 0, st, view.head.w, (size_t)9 * 16 * F, hmx);
+            hipLaunchKernelGGL(k_restage_head_split, dim3(32), dim3(256), 0, st, view.head.w, n->sets[k].head_x2, n->sets[k].head_x2sc, (const unsigned*)hmx, F);
+        }
         TG_HIP(ctx, hipGetLastError());
     } else if (n->prec >= 1) {
         // stage-ordered fp16 copies, converted on the device from the blob just uploaded (round to nearest even)
@@ -2546,6 +2682,10 @@ int tg_net_load_arch(tg_ctx* ctx, const char* arch_c, const float* blob, size_t 
             if (prec >= 1) {
                 TG_HIP(ctx, hipMalloc((void**)&w.wh, sizeof(_Float16) * wcopy * (prec == 3 ? 2 : 1)));
                 if (prec == 3) TG_HIP(ctx, hipMalloc((void**)&w.wsc, sizeof(float) * 2 * (size_t)(2 * NB + 1)));
+                if (prec == 3 && F == 128) {                                         // split-precision head conv (k_head_gemm_x2)
+                    TG_HIP(ctx, hipMalloc((void**)&w.head_x2, sizeof(_Float16) * 64 * (size_t)F * 2));
+                    TG_HIP(ctx, hipMalloc((void**)&w.head_x2sc, sizeof(float) * 2));
+                }
                 if (prec == 3 && any_att && F == 128 && S == 9) {                    // k_attention_x3 (its weight image must fit LDS)
                     size_t n_att = pol ? 1 : 0; for (char c : trunk) n_att += c == 'A';
                     TG_HIP(ctx, hipMalloc((void**)&w.att_h, sizeof(_Float16) * n_att * ((size_t)F / 16 * Wq * 32)));
@@ -2656,7 +2796,7 @@ void tg_net_destroy(tg_ctx* ctx) {
     if (n->pending) (void)hipEventSynchronize(n->loaded);
     void* ptrs[] = {n->bufA, n->bufB, n->bufH, n->x0, n->hc, n->own, n->bufQ, n->hca, n->bufAct, n->act16, n->h16, n->x0h, n->tile_ctr, n->range};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    for (Net::WeightSet& w : n->sets) { void* q[] = {w.blob, w.wstage, w.wh, w.stem_h, w.head_h, w.wsc, w.head_g, w.head_ag, w.att_h, w.att_sc}; for (void* p : q) if (p) (void)hipFree(p); }
+    for (Net::WeightSet& w : n->sets) { void* q[] = {w.blob, w.wstage, w.wh, w.stem_h, w.head_h, w.wsc, w.head_g, w.head_ag, w.att_h, w.att_sc, w.head_x2, w.head_x2sc}; for (void* p : q) if (p) (void)hipFree(p); }
     if (n->side) (void)hipStreamDestroy(n->side);
     if (n->loaded) (void)hipEventDestroy(n->loaded);
     if (n->swapped) (void)hipEventDestroy(n->swapped);

@@ -226,16 +226,22 @@ def targets_for_game(env, final_state, observations, pis, players, board_size=9)
     return out
 
 
-def policy_evaluate(env, evaluate_train, evaluate_eval, n_games, seed, num_simulation=210, board_size=9):
+def policy_evaluate(env, evaluate_train, evaluate_eval, n_games, seed, num_simulation=210, board_size=9, shared_stream=False,
+                    return_rng=False):
     """SelfPlay.policy_evaluate (self_play.py:986-1040): n_games between the train agent and the evaluation agent, the train
     agent's colour alternating from BLACK, every move by select_action; both agents draw from one stream (the reference's
-    global np.random).  The reference never seeds; the parity harness seeds the stream with seed + i at the start of game i.
-    Returns (winners[n_games], colours[n_games], win_ratio)."""
+    global np.random).  The reference never seeds; the parity harness seeds the stream with seed + i at the start of game i
+    (what the batched engine does: its games run concurrently, so each owns a stream).  shared_stream=True is the reference's own
+    form -- ONE stream seeded once and carried from game to game -- which tests/golden/policy_evaluate.json (recorded from the
+    reference's policy_evaluate itself) pins.  Returns (winners[n_games], colours[n_games], win_ratio[, the stream])."""
     BLACK, WHITE = 1, 2
     color = BLACK
     winners, colours = [], []
+    one = np.random.RandomState(int(seed) % (2 ** 32)) if shared_stream else None
+    rng = one
     for i in range(n_games):
-        rng = np.random.RandomState(int(seed + i) % (2 ** 32))
+        if not shared_stream:
+            rng = np.random.RandomState(int(seed + i) % (2 ** 32))
         train = OracleSearch(env, evaluate_train, rng, num_simulation=num_simulation, board_size=board_size)
         evalu = OracleSearch(env, evaluate_eval, rng, num_simulation=num_simulation, board_size=board_size)
         bots = {BLACK: train, WHITE: evalu} if color == BLACK else {BLACK: evalu, WHITE: train}
@@ -246,4 +252,5 @@ def policy_evaluate(env, evaluate_train, evaluate_eval, n_games, seed, num_simul
         winners.append(env.getWinner(state)); colours.append(color)
         color = BLACK + WHITE - color
     winners, colours = np.array(winners), np.array(colours)
-    return winners, colours, float((winners == colours).sum()) / n_games
+    ratio = float((winners == colours).sum()) / n_games
+    return (winners, colours, ratio, rng) if return_rng else (winners, colours, ratio)

@@ -345,3 +345,30 @@ def test_tree_pool_is_shared_accounted_and_survives_exhaustion():
     t2 = tiny.pool_stats()
     assert t2["pool_in_use"] <= t2["pool_slots"] and t2["pool_high_water"] <= t2["pool_slots"]
     roomy.close(); tiny.close()
+
+
+def test_policy_evaluate_against_the_reference_recording(golden_dir):
+    """Row f1 against the reference itself: for single evaluation games the reference's one NumPy stream and this engine's per-game
+    streams (seed + i) are the same stream, so SelfPlay.policy_evaluate must return what the reference's policy_evaluate returned in
+    tests/golden/policy_evaluate.json -- win ratio, both info strings, and the promotion it wrote (or did not write) to the storage."""
+    import json
+    import os
+    from transgo_amd.configure import Config
+    from transgo_amd.self_play import SelfPlay
+    from transgo_amd.shared_storage import SharedStorage
+    fns = {"sharp": evaluators.sharp, "flat": evaluators.flat}
+    with open(os.path.join(golden_dir, "policy_evaluate.json")) as f:
+        cases = [c for c in json.load(f)["cases"] if c["n_games"] == 1]
+    assert len(cases) >= 2 and {bool(c["promoted"]) for c in cases} == {True, False}
+    for c in cases:
+        cfg = Config(num_simulation=c["sims"], max_step=c["max_step"], komi=c["komi"])
+        st = SharedStorage({"weights": c["train"], "evaluate_weights": c["evalu"], "evaluate_score": 100}, cfg)
+        sp = SelfPlay(cfg, n_games=2, evaluator=evaluators.flat)
+        ratio, info2, info3 = sp.policy_evaluate(1, st, seed=c["seed"], evaluators={"train": fns[c["train"]], "eval": fns[c["evalu"]]})
+        assert ratio == c["ratio"] and info2 == c["info2"] and info3 == c["info3"]
+        assert list(sp.last_evaluation["winners"]) == c["winners"] and list(sp.last_evaluation["colours"]) == c["colours"]
+        if c["promoted"]:
+            assert st.get_info("evaluate_score") == c["score_written"][0] and st.get_info("evaluate_weights") == c["train"]
+        else:
+            assert st.get_info("evaluate_score") == 100 and st.get_info("evaluate_weights") == c["evalu"]
+        sp.worker.engine.close()

@@ -99,3 +99,26 @@ def test_select_action_matches_reference(golden_dir):
         raw = np.array([bot.root.kids[i].n if i in bot.root.kids else 0 for i in range(82)])
         assert (raw == b["counts"][ply]).all() and a == want and rng.get_state()[2] == b["pos"][ply], ply
         state, _ = env.step(state, a)
+
+
+def test_policy_evaluate_loop_matches_the_reference(golden_dir):
+    """Row f1: the evaluation-match loop of self_play.py:986-1040 -- colour alternation from BLACK, every move by select_action, both
+    agents on ONE NumPy stream carried from game to game, winner by getWinner, win ratio -- against what the reference's own
+    policy_evaluate did (tests/golden/gen_policy_evaluate.py: fake storage actors, exact stand-in evaluators): winner and train colour
+    of every game, the ratio, the reference's own info strings and the position of the stream afterwards."""
+    import json
+    from oracle.wp_mcts import policy_evaluate
+    fns = {"sharp": evaluators.sharp, "flat": evaluators.flat}
+    with open(os.path.join(golden_dir, "policy_evaluate.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) >= 5 and any(c["promoted"] for c in cases) and any(1 in c["winners"] for c in cases)
+    for c in cases:
+        env = OracleGoEnv(max_step=c["max_step"], komi=c["komi"])
+        w, col, ratio, rng = policy_evaluate(env, fns[c["train"]], fns[c["evalu"]], c["n_games"], c["seed"], num_simulation=c["sims"],
+                                             shared_stream=True, return_rng=True)
+        assert list(w) == c["winners"] and list(col) == c["colours"] and ratio == c["ratio"], (c["train"], c["evalu"], c["seed"])
+        assert rng.get_state()[2] == c["rng_pos"]
+        assert c["info2"] == "simulate round: {},  winer is : {},  model player is : {}\n".format(c["n_games"], c["winners"][-1], c["colours"][-1])
+        win = sum(int(a == b) for a, b in zip(c["winners"], c["colours"]))
+        assert c["info3"] == "evaluate_score:100, win: {}, lose: {}\n".format(win, c["n_games"] - win)
+        assert c["promoted"] == (["evaluate_score", "evaluate_weights"] if ratio == 1 else []) and c["score_written"] == ([200] if ratio == 1 else [])

@@ -32,6 +32,7 @@ for i in range(STEPS):
               f"arena high-water {st['max_slots']}, {st['sims'] / (time.time() - t0):.0f} sims/s", flush=True)
 st = sp.engine.stats()
 assert st["errors"] == 0 and sp.games_dropped == 0, (st, sp.games_dropped)
-print("arena high-water", st["max_slots"], "slots; truncated tree blocks", st["truncated_blocks"], "; games dropped", sp.games_dropped)
+print("largest tree", st["max_slots"], "slots; pool", st["pool_slots"], "slots, high-water", st["pool_high_water"], f"({st['pool_high_water'] / max(1, st['pool_slots']):.1%}), ran empty",
+      st["pool_exhausted"], "; truncated tree blocks", st["truncated_blocks"], "; games dropped", sp.games_dropped, "; fp16 overflows", st["fp16_overflows"])
 assert fin >= G * (STEPS // (MAXSTEP + 5)), (fin, "fewer finished games than the ply limit guarantees")
 print("soak ok:", fin, "games; black/white wins", winners[1], winners[2], "; mean length", round(float(np.mean(lens)), 1) if lens else 0)
